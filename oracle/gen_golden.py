@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN CODE in the build container.
+
+Runs only where /root/reference exists (never on the GPU box).  Nothing of the reference's text is
+written into the repository: the scripts are read from /root/reference at run time, executed, and only
+their input/output ARRAYS (or SHA-256 digests of the large ones) are stored.
+
+How the reference is made to run here:
+  * `daisy i flann.py` and `python bcd.py` are flat scripts with hard-coded KITTI sizes.  The four
+    size assignments (picw/pich/cellw/cellh) are replaced in the text before exec().
+  * cv2 and pyflann are not installed.  `python bcd.py` imports but never uses them -> empty modules.
+    `daisy i flann.py` uses cv2.imread / KeyPoint / xfeatures2d.DAISY and pyflann.FLANN; those calls are
+    the two places where third-party arithmetic enters, and here they are fed from the oracle:
+    DAISY -> oracle.daisy (PARITY UNPINNED vs OpenCV), FLANN -> oracle.knn_points (exact canonical search,
+    PARITY UNPINNED vs FLANN's approximate search).  Everything the reference itself computes around
+    them (proposal slots, [dy,dx], truncated L1 costs, WTA labels, neighbour sampling + dedupe + cost,
+    compat bit packing, the BCD dynamic programme, the sweep schedule, labels->flow) runs unmodified.
+  * np.random.normal is replaced, for the duration of the run, by a replayer that feeds the build's
+    counter-based draws (Philox keyed by pixel/attempt) in the order the reference consumes them.
+  * postprocessing.py imports cleanly and is called as is.
+
+Usage: python oracle/gen_golden.py   (writes tests/golden/ref_<name>.npz)
+"""
+import contextlib
+import hashlib
+import importlib
+import io
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import oracle as O  # noqa: E402
+
+synth = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.synth")
+dio = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.flowio")
+
+
+def digest(a, dtype):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=dtype).tobytes()).hexdigest()
+
+
+def patched_source(name, H, W, cellh, cellw):
+    src = open(os.path.join(REF, name)).read()
+    for old, new in (("picw = 1241", f"picw = {W}"), ("pich = 375", f"pich = {H}"),
+                     ("cellw = 73", f"cellw = {cellw}"), ("cellh = 25", f"cellh = {cellh}")):
+        assert src.count(old) == 1, (name, old)
+        src = src.replace(old, new)
+    return src
+
+
+class NormalReplayer:
+    """Feeds int(np.random.normal(c, sigma)) == trunc(c + off + 0.5) with off from the build's RNG, following
+    the control flow of nasumicni (daisy i flann.py:209-233): x outer, y inner, 25 counted tries per pixel."""
+
+    def __init__(self, p):
+        self.p, self.thr = p, O.gauss_thresholds(p.sigma)
+        self.x = self.y = 0
+        self.attempt = 0
+        self.counted = 0
+        self.expect_x = False
+        self.rnd = None
+
+    def __call__(self, loc, scale):
+        p = self.p
+        assert scale == p.sigma
+        if not self.expect_x:
+            if self.counted == p.ngauss:            # reference moved on to the next pixel
+                self.counted, self.attempt = 0, 0
+                self.y += 1
+                if self.y == p.pich:
+                    self.y, self.x = 0, self.x + 1
+            assert loc == self.y, (loc, self.y, self.x)
+            self.rnd = O.philox(self.y * p.picw + self.x, self.attempt, p.seed)
+            self.attempt += 1
+            off = O.gauss_offset(self.thr, int(self.rnd[0]))
+            t = int(loc + off + 0.5)
+            self.expect_x = 0 <= t < p.pich
+            return loc + off + 0.5
+        assert loc == self.x
+        off = O.gauss_offset(self.thr, int(self.rnd[1]))
+        t = int(loc + off + 0.5)
+        self.expect_x = False
+        if 0 <= t < p.picw:
+            self.counted += 1
+        return loc + off + 0.5
+
+
+def run_reference_pass(p, img_first, img_second, idx, backward, bcd_times, workdir):
+    """Executes `daisy i flann.py idx backward 1` then `python bcd.py idx backward bcd_times` in workdir."""
+    H, W = p.pich, p.picw
+    images = {f"_1{backward}.png": img_first, f"_1{1 - backward}.png": img_second}
+
+    cv2 = types.ModuleType("cv2")
+    cv2.imread = lambda path, *a: images[path[-7:]].copy()
+    cv2.KeyPoint = lambda x, y, s: (x, y, s)
+
+    class _Daisy:
+        def compute(self, picture, kp):
+            assert len(kp) == H * W and kp[1][:2] == (1, 0)          # y-major keypoint order (:70)
+            return kp, O.daisy(picture).reshape(H * W, 68)
+    cv2.xfeatures2d = types.SimpleNamespace(DAISY_create=lambda **kw: _Daisy())
+
+    pyflann = types.ModuleType("pyflann")
+
+    class _Flann:
+        def build_index(self, pts):
+            self.pts = np.ascontiguousarray(pts, np.float32)
+            return {}
+
+        def nn_index(self, qpts, num_neighbors):
+            idx_, dist_ = O.knn_points(qpts, self.pts, num_neighbors)
+            return idx_[None, :], dist_[None, :]
+    pyflann.FLANN = _Flann
+
+    saved = {k: sys.modules.get(k) for k in ("cv2", "pyflann")}
+    saved_normal, saved_argv, saved_cwd = np.random.normal, sys.argv, os.getcwd()
+    sys.modules["cv2"], sys.modules["pyflann"] = cv2, pyflann
+    np.random.normal = NormalReplayer(p)
+    os.chdir(workdir)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            sys.argv = ["daisy i flann.py", str(idx), str(backward), "1"]
+            exec(compile(patched_source("daisy i flann.py", H, W, p.cellh, p.cellw), "daisy i flann.py", "exec"),
+                 {"__name__": "__main__"})
+            np.random.normal = saved_normal
+            sys.modules["cv2"], sys.modules["pyflann"] = types.ModuleType("cv2"), types.ModuleType("pyflann")
+            sys.argv = ["python bcd.py", str(idx), str(backward), str(bcd_times)]
+            exec(compile(patched_source("python bcd.py", H, W, p.cellh, p.cellw), "python bcd.py", "exec"),
+                 {"__name__": "__main__"})
+    finally:
+        np.random.normal, sys.argv = saved_normal, saved_argv
+        os.chdir(saved_cwd)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    P = "1%02d" % idx
+    ld = lambda n: np.load(os.path.join(workdir, n))
+    out = dict(
+        proposals=ld(f"Daisy output slike {P} backward={backward} proposals_nakon_gausa.npy"),
+        lcosts=ld(f"Daisy output slike {P} backward={backward} lcosts_nakon_gausa.npy"),
+        nprop=ld(f"Daisy output slike {P} backward={backward} nprop.npy"),
+        packedksets=ld(f"Daisy output slike {P} backward={backward} packedksets.npy"),
+        labels=[ld(f"Bestlabels fajl slike {P} backward={backward} posle {w:02d} BCD.npy") for w in range(bcd_times + 1)],
+        flows=[ld(f"Gotova flow slika {P} backward={backward} posle {w:02d} BCD.npy") for w in range(bcd_times + 1)],
+    )
+    return out
+
+
+def make_fixture(name, H, W, cellh, cellw, seed, bcd_times=3, idx=6):
+    p = O.make_params(H, W, cellh, cellw, seed=seed)
+    img1, img2, gt = synth.make_pair(H, W, seed=seed, amp_x=0.12 * W, amp_y=0.12 * H)
+    store = dict(name=name, H=H, W=W, cellh=cellh, cellw=cellw, seed=np.uint64(seed), bcd_times=bcd_times,
+                 img1=img1, img2=img2, gt=gt.astype(np.float32))
+    fields = {}
+    for backward in (0, 1):
+        a, b = (img1, img2) if backward == 0 else (img2, img1)
+        with tempfile.TemporaryDirectory() as wd:
+            ref = run_reference_pass(p, a, b, idx, backward, bcd_times, wd)
+            # keep the flow files for the postprocessing run below
+            fields[backward] = ref["flows"][-1]
+        k = f"b{backward}_"
+        d1, d2 = O.daisy(a), O.daisy(b)
+        store[k + "d1_sha"] = digest(d1, np.float32)
+        store[k + "d2_sha"] = digest(d2, np.float32)
+        # G1 (state "posle 00", before nasumicni): WTA labels and flow
+        store[k + "labels00"] = ref["labels"][0].astype(np.int16)
+        store[k + "flow00"] = ref["flows"][0].astype(np.int16)
+        # G2 after nasumicni
+        store[k + "nprop"] = ref["nprop"].astype(np.int16)
+        store[k + "proposals_sha"] = digest(ref["proposals"], np.int64)
+        store[k + "lcosts_sha"] = digest(ref["lcosts"], np.float64)
+        store[k + "proposals_rows"] = ref["proposals"][:2].astype(np.int16)      # sample rows for diagnosis
+        store[k + "lcosts_rows"] = ref["lcosts"][:2]
+        # G3 compat bit matrices
+        store[k + "packedksets_sha"] = digest(ref["packedksets"], np.uint8)
+        store[k + "packedksets_px"] = ref["packedksets"][1, 1]
+        # G4 labels after every sweep
+        for w in range(1, bcd_times + 1):
+            store[k + f"labels{w:02d}"] = ref["labels"][w].astype(np.int16)
+            store[k + f"flow{w:02d}_sha"] = digest(ref["flows"][w], np.float64)
+        print(name, "backward", backward, "done; nprop range", ref["nprop"].min(), ref["nprop"].max())
+    # G5 forward/backward consistency through the reference's postprocessing.py
+    sys.path.insert(0, REF)
+    try:
+        post = importlib.import_module("postprocessing")
+        with tempfile.TemporaryDirectory() as wd:
+            f0, f1, so = (os.path.join(wd, n) for n in ("fwd.npy", "bwd.npy", "sparse.npy"))
+            np.save(f0, fields[0]); np.save(f1, fields[1])
+            for tresh in (1, 3):
+                post.postProcessing(f0, f1, tresh, so)
+                store[f"sparse_t{tresh}"] = np.load(so)
+    finally:
+        sys.path.remove(REF)
+    # G6 .flo: bytes written by the build's writer, parsed by the reference's reader (visualization.py:9-29)
+    lines = open(os.path.join(REF, "visualization.py")).read().splitlines()
+    ns = {"np": np}
+    exec("\n".join(lines[8:29]), ns)
+    with tempfile.TemporaryDirectory() as wd:
+        path = os.path.join(wd, "t.flo")
+        dio.write_flo(path, fields[0])
+        store["flo_parsed_by_reference"] = ns["read_flo_file"](path)
+        store["flo_bytes"] = np.frombuffer(open(path, "rb").read(), np.uint8)
+    out = os.path.join(ROOT, "tests", "golden", f"ref_{name}.npz")
+    np.savez_compressed(out, **store)
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    make_fixture("a40x48_c5x6", 40, 48, 5, 6, seed=11)
+    make_fixture("b36x40_c9x8", 36, 40, 9, 8, seed=23)
