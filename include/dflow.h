@@ -1,0 +1,115 @@
+/*
+ * dflow.h -- C-ABI of libdflow.so: the MI355X (gfx950) dense discrete optical-flow stage.
+ *
+ * The reference (pfe-rs/lk-s-2022-estimacija-pokreta) has no FFI: its hot path is two flat Python scripts
+ * that talk through .npy files.  Each entry point below replaces the reference function(s) named next to
+ * it; INTEGRATION.md shows the ctypes binding a maintainer would add to the reference scripts.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  All d_* pointers are DEVICE pointers owned by the caller.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous with
+ *     respect to the host and ordered on that stream; the library never synchronises and never allocates
+ *     device memory: scratch comes from the caller's workspace (dflow_workspace_bytes).
+ *   - Return 0 on success, a negative DFLOW_E* code otherwise; dflow_last_error() gives the message
+ *     (thread-local).  No global state; re-entrant across devices.
+ *
+ * Device layouts (H = pich, W = picw, LP = label_pitch >= maxnprop, multiple of 4)
+ *   image      uint8   (H,W,3)   BGR, as cv2.imread returns it            daisy i flann.py:26-27,52-53
+ *   descr      float32 (H,W,68)  row y*W+x = keypoint order               daisy i flann.py:69-77
+ *   proposals  uint32  (H,W,LP)  one label = int16 dy | int16 dx << 16,   daisy i flann.py:89 (int64 (H,W,150,2), -1 fill)
+ *                                unused slots 0xFFFFFFFF (= [-1,-1])
+ *   lcosts     float32 (H,W,LP)  unused slots 1000.0f                     daisy i flann.py:90 (float64; values are float32-exact)
+ *   nprop      int32   (H,W)                                              daisy i flann.py:91
+ *   bestlabels int32   (H,W)                                              daisy i flann.py:95
+ *   flow       float32 (H,W,2)   [dy,dx]                                  python bcd.py:90-95 (float64; values are small integers)
+ *   sparse     float32 (H,W,3)   [U=dx, V=dy, valid]                      postprocessing.py:7-17,123-135
+ */
+#ifndef DFLOW_H
+#define DFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFLOW_VERSION 1
+#define DFLOW_DESC 68            /* (4 rings * 4 angles + 1) * 4 bins, daisy i flann.py:66 */
+#define DFLOW_MAX_LABELS 160     /* kernels are built for maxnprop <= 160 (reference: 150) */
+
+#define DFLOW_OK 0
+#define DFLOW_EINVAL (-1)        /* bad parameter / null pointer / unsupported geometry */
+#define DFLOW_ENOSPC (-2)        /* workspace too small */
+#define DFLOW_EHIP (-3)          /* HIP runtime error (launch failure, no device) */
+
+/* Algorithm constants.  Field-for-field the module globals of the reference scripts. */
+typedef struct dflow_params {
+    int32_t pich, picw;          /* daisy i flann.py:34-35 */
+    int32_t cellh, cellw;        /* daisy i flann.py:42-43; ragged last row/column of cells absorbs the remainder */
+    int32_t maxnprop;            /* daisy i flann.py:88   (150) */
+    int32_t knn;                 /* daisy i flann.py:172  (5; kernels require 5) */
+    int32_t window;              /* daisy i flann.py:167-168 (2 cells each side) */
+    int32_t ngauss;              /* daisy i flann.py:207  (25) */
+    int32_t tpsi;                /* daisy i flann.py:47   (8)  */
+    int32_t max_attempts;        /* bound on draws per pixel in the neighbour sampler (65536) */
+    float tphi;                  /* daisy i flann.py:46   (2.5) */
+    float sigma;                 /* daisy i flann.py:208  (8)  */
+    double lamda;                /* daisy i flann.py:48   (0.05) */
+    uint64_t seed;               /* key of the counter-based sampler (reference: unseeded np.random, :219) */
+    int32_t label_pitch;         /* LP, elements per pixel in proposals/lcosts (160) */
+    int32_t reserved;
+} dflow_params;
+
+int dflow_version(void);
+const char *dflow_last_error(void);
+
+/* Fills *p with the reference constants for the given geometry. */
+void dflow_default_params(dflow_params *p, int32_t pich, int32_t picw, int32_t cellh, int32_t cellw);
+
+/* Scratch bytes any entry point may need for these parameters (one buffer serves all stages). */
+size_t dflow_workspace_bytes(const dflow_params *p);
+
+/* izracunajDaisy, daisy i flann.py:69-77 (cv2.xfeatures2d.DAISY_create(radius=5,q_radius=4,q_theta=4,q_hist=4)
+ * .compute on every pixel).  d_bgr (H,W,3) uint8 -> d_descr (H,W,68) float32. */
+int dflow_daisy(const dflow_params *p, const uint8_t *d_bgr, float *d_descr,
+                void *d_ws, size_t ws_bytes, void *stream);
+
+/* napraviCD2 + generisi, daisy i flann.py:144-189: per-cell exact 5-NN proposals, truncated-L1 costs,
+ * WTA labels.  Initialises and fills proposals/lcosts/nprop/bestlabels. */
+int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2,
+                        uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels,
+                        void *d_ws, size_t ws_bytes, void *stream);
+
+/* nasumicni, daisy i flann.py:205-233: appends up to ngauss neighbour proposals per pixel (in place).
+ * d_bestlabels must still hold the WTA labels written by dflow_knn_proposals. */
+int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2,
+                              uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop,
+                              const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream);
+
+/* One of the four loops of ceoBCD's body, python bcd.py:265-277 (phase 0 even columns top->bottom,
+ * 1 even rows right->left, 2 odd columns bottom->top, 3 odd rows left->right); every chain is one call of
+ * bcd(), python bcd.py:101-257, with pakovanje's compat test (daisy i flann.py:256-309) evaluated on the fly.
+ * Updates d_bestlabels in place. */
+int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts,
+                    const int32_t *d_nprop, int32_t *d_bestlabels, int32_t phase,
+                    void *d_ws, size_t ws_bytes, void *stream);
+
+/* One iteration of ceoBCD's loop (all four phases), python bcd.py:264-277. */
+int dflow_bcd_sweep(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts,
+                    const int32_t *d_nprop, int32_t *d_bestlabels,
+                    void *d_ws, size_t ws_bytes, void *stream);
+
+/* vratiKonacniFlow, python bcd.py:90-95 / daisy i flann.py:192-197. */
+int dflow_labels_to_flow(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_bestlabels,
+                         float *d_flow, void *stream);
+
+/* postProcessing = FlowImage.ucitajFlow x2 + fowardBackwardConsistency, postprocessing.py:7-17,79-135
+ * (including its transposed indexing).  d_fwd/d_bwd (H,W,2) [dy,dx] -> d_sparse (H,W,3) [U,V,valid]. */
+int dflow_fb_consistency(const dflow_params *p, const float *d_fwd, const float *d_bwd, float tresh,
+                         float *d_sparse, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFLOW_H */

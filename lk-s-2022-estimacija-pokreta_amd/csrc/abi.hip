@@ -1,0 +1,134 @@
+// C-ABI entry points of libdflow.so (declared in include/dflow.h): parameter validation, workspace
+// accounting and dispatch to the per-stage launchers.  No torch types, no allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "dflow_common.h"
+
+static thread_local char g_err[512] = "";
+
+int dflow_set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int dflow_check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dflow_set_error(DFLOW_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return DFLOW_OK;
+}
+
+int dflow_check_params(const dflow_params *p)
+{
+    if (!p) return dflow_set_error(DFLOW_EINVAL, "params is NULL");
+    if (p->pich < 8 || p->picw < 8 || p->pich > 8192 || p->picw > 8192)
+        return dflow_set_error(DFLOW_EINVAL, "image size %dx%d outside [8,8192]", p->picw, p->pich);
+    if (p->cellh < 1 || p->cellw < 1 || p->cellh > p->pich || p->cellw > p->picw)
+        return dflow_set_error(DFLOW_EINVAL, "cell size %dx%d does not fit the image", p->cellw, p->cellh);
+    if (p->knn != 5) return dflow_set_error(DFLOW_EINVAL, "knn=%d unsupported (kernels are built for 5)", p->knn);
+    if (p->cellh * p->cellw < p->knn) return dflow_set_error(DFLOW_EINVAL, "cells hold fewer than knn points");
+    if (p->window < 0 || p->window > 2) return dflow_set_error(DFLOW_EINVAL, "window=%d outside [0,2]", p->window);
+    if (p->ngauss < 0 || p->ngauss > 64) return dflow_set_error(DFLOW_EINVAL, "ngauss=%d outside [0,64]", p->ngauss);
+    int maxknn = (2 * p->window + 1) * (2 * p->window + 1) * p->knn;
+    if (p->maxnprop < maxknn + p->ngauss || p->maxnprop > DFLOW_MAX_LABELS)
+        return dflow_set_error(DFLOW_EINVAL, "maxnprop=%d must be in [%d,%d]", p->maxnprop, maxknn + p->ngauss, DFLOW_MAX_LABELS);
+    if (p->label_pitch < p->maxnprop || p->label_pitch % 4 != 0 || p->label_pitch > 256)
+        return dflow_set_error(DFLOW_EINVAL, "label_pitch=%d must be a multiple of 4 in [maxnprop,256]", p->label_pitch);
+    if (p->tpsi < 1 || p->tpsi > 4096) return dflow_set_error(DFLOW_EINVAL, "tpsi=%d outside [1,4096]", p->tpsi);
+    if (!(p->sigma > 0.0f) || p->sigma > 8.0f) return dflow_set_error(DFLOW_EINVAL, "sigma=%g outside (0,8]", (double)p->sigma);
+    if (p->max_attempts < p->ngauss) return dflow_set_error(DFLOW_EINVAL, "max_attempts < ngauss");
+    return DFLOW_OK;
+}
+
+extern "C" {
+
+int dflow_version(void) { return DFLOW_VERSION; }
+
+const char *dflow_last_error(void) { return g_err; }
+
+void dflow_default_params(dflow_params *p, int32_t pich, int32_t picw, int32_t cellh, int32_t cellw)
+{
+    memset(p, 0, sizeof(*p));
+    p->pich = pich; p->picw = picw; p->cellh = cellh; p->cellw = cellw;
+    p->maxnprop = 150; p->knn = 5; p->window = 2; p->ngauss = 25; p->tpsi = 8; p->max_attempts = 1 << 16;
+    p->tphi = 2.5f; p->sigma = 8.0f; p->lamda = 0.05; p->seed = 0; p->label_pitch = 160;
+}
+
+size_t dflow_workspace_bytes(const dflow_params *p)
+{
+    if (dflow_check_params(p) != DFLOW_OK) return 0;
+    size_t a = daisy_ws_bytes(p), b = bcd_ws_bytes(p);
+    return (a > b ? a : b) + 256;
+}
+
+#define CHECK_PTR(x) do { if (!(x)) return dflow_set_error(DFLOW_EINVAL, "%s: %s is NULL", __func__, #x); } while (0)
+#define CHECK_WS(need) do { if (!d_ws || ws_bytes < (need)) \
+    return dflow_set_error(DFLOW_ENOSPC, "%s: workspace %zu < %zu bytes", __func__, ws_bytes, (size_t)(need)); } while (0)
+
+int dflow_daisy(const dflow_params *p, const uint8_t *d_bgr, float *d_descr, void *d_ws, size_t ws_bytes, void *stream)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_bgr); CHECK_PTR(d_descr); CHECK_WS(daisy_ws_bytes(p));
+    return launch_daisy(p, d_bgr, d_descr, d_ws, (hipStream_t)stream);
+}
+
+int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,
+                        float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream)
+{
+    (void)d_ws; (void)ws_bytes;
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_descr1); CHECK_PTR(d_descr2); CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels);
+    return launch_knn(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, (hipStream_t)stream);
+}
+
+int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,
+                              float *d_lcosts, int32_t *d_nprop, const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes,
+                              void *stream)
+{
+    (void)d_ws; (void)ws_bytes;
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_descr1); CHECK_PTR(d_descr2); CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels);
+    return launch_neighbour(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, (hipStream_t)stream);
+}
+
+int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts, const int32_t *d_nprop,
+                    int32_t *d_bestlabels, int32_t phase, void *d_ws, size_t ws_bytes, void *stream)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels); CHECK_WS(bcd_ws_bytes(p));
+    if (phase < 0 || phase > 3) return dflow_set_error(DFLOW_EINVAL, "phase=%d outside [0,3]", phase);
+    return launch_bcd_phase(p, d_proposals, d_lcosts, d_nprop, d_bestlabels, phase, d_ws, (hipStream_t)stream);
+}
+
+int dflow_bcd_sweep(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts, const int32_t *d_nprop,
+                    int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream)
+{
+    for (int ph = 0; ph < 4; ph++) {
+        int rc = dflow_bcd_phase(p, d_proposals, d_lcosts, d_nprop, d_bestlabels, ph, d_ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DFLOW_OK;
+}
+
+int dflow_labels_to_flow(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_bestlabels, float *d_flow,
+                         void *stream)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_proposals); CHECK_PTR(d_bestlabels); CHECK_PTR(d_flow);
+    return launch_labels_to_flow(p, d_proposals, d_bestlabels, d_flow, (hipStream_t)stream);
+}
+
+int dflow_fb_consistency(const dflow_params *p, const float *d_fwd, const float *d_bwd, float tresh, float *d_sparse,
+                         void *stream)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_fwd); CHECK_PTR(d_bwd); CHECK_PTR(d_sparse);
+    return launch_fb_consistency(p, d_fwd, d_bwd, tresh, d_sparse, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Shared host/device helpers of libdflow.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dflow.h"
+
+#define DFLOW_FILL_PROPOSAL 0xFFFFFFFFu /* [-1,-1], daisy i flann.py:89 */
+#define DFLOW_FILL_COST 1000.0f         /* daisy i flann.py:90 */
+
+// Geometry of the cell grid (daisy i flann.py:42-43,85-86; ragged last cells: DESIGN.md "Geometry").
+struct Geom {
+    int H, W, ch, cw, ncx, ncy, win;
+    __host__ __device__ int cellx(int x) const { int c = x / cw; return c < ncx ? c : ncx - 1; }
+    __host__ __device__ int celly(int y) const { int c = y / ch; return c < ncy ? c : ncy - 1; }
+    __host__ __device__ int x0(int ci) const { return ci * cw; }
+    __host__ __device__ int y0(int cj) const { return cj * ch; }
+    __host__ __device__ int x1(int ci) const { return ci == ncx - 1 ? W : (ci + 1) * cw; }
+    __host__ __device__ int y1(int cj) const { return cj == ncy - 1 ? H : (cj + 1) * ch; }
+};
+
+static inline Geom make_geom(const dflow_params *p)
+{
+    Geom g;
+    g.H = p->pich; g.W = p->picw; g.ch = p->cellh; g.cw = p->cellw;
+    g.ncx = p->picw / p->cellw; g.ncy = p->pich / p->cellh; g.win = p->window;
+    return g;
+}
+
+// label packing: int16 dy | int16 dx << 16
+__host__ __device__ static inline uint32_t pack_flow(int dy, int dx)
+{
+    return (uint32_t)(uint16_t)(int16_t)dy | ((uint32_t)(uint16_t)(int16_t)dx << 16);
+}
+__host__ __device__ static inline int flow_dy(uint32_t f) { return (int)(int16_t)(f & 0xFFFFu); }
+__host__ __device__ static inline int flow_dx(uint32_t f) { return (int)(int16_t)(f >> 16); }
+
+// |dy-dy'| + |dx-dx'| of two packed labels (purepsi, daisy i flann.py:114-115): flip the sign bits so that the
+// int16 halves order like uint16, then one v_sad_u16.
+__device__ static inline uint32_t flow_bias(uint32_t f) { return f ^ 0x80008000u; }
+__device__ static inline uint32_t flow_l1_biased(uint32_t a, uint32_t b) { return __builtin_amdgcn_sad_u16(a, b, 0u); }
+
+// numpy float32 pairwise-sum order for 68 contiguous values (np.sum at daisy i flann.py:179,229)
+__device__ static inline float np_pairwise_sum68(const float *a)
+{
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+#pragma unroll
+    for (int i = 8; i < 64; i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = __fadd_rn(r[j], a[i + j]);
+    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+#pragma unroll
+    for (int i = 64; i < DFLOW_DESC; i++) res = __fadd_rn(res, a[i]);
+    return res;
+}
+
+// error plumbing (abi.hip)
+int dflow_set_error(int code, const char *fmt, ...);
+int dflow_check_launch(const char *what);
+int dflow_check_params(const dflow_params *p);
+
+// stage launchers (one per .hip file)
+int launch_daisy(const dflow_params *p, const uint8_t *bgr, float *descr, void *ws, hipStream_t s);
+size_t daisy_ws_bytes(const dflow_params *p);
+int launch_knn(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+               int32_t *nprop, int32_t *bestlabels, hipStream_t s);
+int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+                     int32_t *nprop, const int32_t *bestlabels, hipStream_t s);
+int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop,
+                     int32_t *bestlabels, int phase, void *ws, hipStream_t s);
+size_t bcd_ws_bytes(const dflow_params *p);
+int launch_labels_to_flow(const dflow_params *p, const uint32_t *proposals, const int32_t *bestlabels, float *flow,
+                          hipStream_t s);
+int launch_fb_consistency(const dflow_params *p, const float *fwd, const float *bwd, float tresh, float *sparse,
+                          hipStream_t s);

@@ -1,0 +1,174 @@
+"""Host-side mirror of the reference's hot path on one MI355X.
+
+`DiscreteFlow` keeps the state the reference keeps in module globals (daisy i flann.py:89-95) as device
+tensors and exposes the reference's own function names; each method is one call through the C-ABI
+(include/dflow.h) on torch's current HIP stream.  torch is used for device memory, streams and
+torch.distributed only -- every computation happens in libdflow.so.  No CPU fallback exists.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import flowio
+
+DEFAULT_CELLS = {  # (pich, picw) -> (cellh, cellw)
+    (375, 1241): (25, 73),    # daisy i flann.py:34-35,42-43 (KITTI, exact tiling)
+    (375, 1242): (25, 54),    # discrete_flow.py:22-23,30-31
+    (436, 1024): (27, 64),    # Sintel: 16x16 cells, last cell row absorbs 4 rows
+}
+
+
+def default_cells(pich, picw):
+    if (pich, picw) in DEFAULT_CELLS:
+        return DEFAULT_CELLS[(pich, picw)]
+    return max(5, pich // 15), max(5, picw // 17)   # the reference's 17x15 grid (daisy i flann.py:85-86)
+
+
+class DiscreteFlow:
+    """One (pair, direction) pass: DAISY -> kNN proposals -> neighbour proposals -> BCD sweeps."""
+
+    def __init__(self, pich, picw, cellh=None, cellw=None, device="cuda:0", seed=0, **overrides):
+        if not torch.cuda.is_available():
+            raise _lib.DflowError("no HIP device visible: the dflow hot path has no CPU fallback")
+        if cellh is None or cellw is None:
+            cellh, cellw = default_cells(pich, picw)
+        self.p = _lib.default_params(pich, picw, cellh, cellw, seed=seed, **overrides)
+        _lib.check(0 if _lib.lib().dflow_workspace_bytes(C.byref(self.p)) else -1, "dflow_workspace_bytes")
+        self.device = torch.device(device)
+        H, W, LP = pich, picw, self.p.label_pitch
+        dev = self.device
+        self.descrs1 = torch.empty((H, W, 68), dtype=torch.float32, device=dev)     # daisy i flann.py:80
+        self.descrs2 = torch.empty((H, W, 68), dtype=torch.float32, device=dev)     # :81
+        self.proposals = torch.empty((H, W, LP), dtype=torch.int32, device=dev)     # :89 (packed int16 pairs)
+        self.lcosts = torch.empty((H, W, LP), dtype=torch.float32, device=dev)      # :90
+        self.nprop = torch.empty((H, W), dtype=torch.int32, device=dev)             # :91
+        self.bestlabels = torch.empty((H, W), dtype=torch.int32, device=dev)        # :95
+        self.flow = torch.empty((H, W, 2), dtype=torch.float32, device=dev)
+        self.ws_bytes = int(_lib.lib().dflow_workspace_bytes(C.byref(self.p)))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self._img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _pp(self):
+        return C.byref(self.p)
+
+    # ------------------------------------------------------------------ reference-named stages
+    def izracunajDaisy(self, picture, out=None):
+        """daisy i flann.py:69-77.  picture: (H,W,3) uint8 BGR (numpy or device tensor) -> (H,W,68) f32 tensor."""
+        H, W = self.p.pich, self.p.picw
+        if isinstance(picture, np.ndarray):
+            if picture.shape != (H, W, 3) or picture.dtype != np.uint8:
+                raise ValueError("picture must be uint8 (%d,%d,3)" % (H, W))
+            self._img.copy_(torch.from_numpy(np.ascontiguousarray(picture)))
+            img = self._img
+        else:
+            if tuple(picture.shape) != (H, W, 3) or picture.dtype != torch.uint8 or not picture.is_contiguous():
+                raise ValueError("picture must be a contiguous uint8 (%d,%d,3) tensor" % (H, W))
+            img = picture
+        if out is None:
+            out = torch.empty((H, W, 68), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().dflow_daisy(self._pp(), img.data_ptr(), out.data_ptr(), self.ws.data_ptr(),
+                                          self.ws_bytes, self._stream()), "dflow_daisy")
+        return out
+
+    def load_pair(self, pic3, pic4):
+        """daisy i flann.py:406-407."""
+        self.izracunajDaisy(pic3, out=self.descrs1)
+        self.izracunajDaisy(pic4, out=self.descrs2)
+
+    def set_descriptors(self, descrs1, descrs2):
+        self.descrs1.copy_(torch.as_tensor(descrs1, dtype=torch.float32))
+        self.descrs2.copy_(torch.as_tensor(descrs2, dtype=torch.float32))
+
+    def generisi(self):
+        """napraviCD2 + generisi, daisy i flann.py:144-189."""
+        _lib.check(_lib.lib().dflow_knn_proposals(self._pp(), self.descrs1.data_ptr(), self.descrs2.data_ptr(),
+                                                  self.proposals.data_ptr(), self.lcosts.data_ptr(),
+                                                  self.nprop.data_ptr(), self.bestlabels.data_ptr(),
+                                                  self.ws.data_ptr(), self.ws_bytes, self._stream()),
+                   "dflow_knn_proposals")
+
+    def nasumicni(self):
+        """daisy i flann.py:205-233."""
+        _lib.check(_lib.lib().dflow_neighbour_proposals(self._pp(), self.descrs1.data_ptr(), self.descrs2.data_ptr(),
+                                                        self.proposals.data_ptr(), self.lcosts.data_ptr(),
+                                                        self.nprop.data_ptr(), self.bestlabels.data_ptr(),
+                                                        self.ws.data_ptr(), self.ws_bytes, self._stream()),
+                   "dflow_neighbour_proposals")
+
+    def bcd_phase(self, phase):
+        """One of the four chain loops of ceoBCD, python bcd.py:265-277."""
+        _lib.check(_lib.lib().dflow_bcd_phase(self._pp(), self.proposals.data_ptr(), self.lcosts.data_ptr(),
+                                              self.nprop.data_ptr(), self.bestlabels.data_ptr(), phase,
+                                              self.ws.data_ptr(), self.ws_bytes, self._stream()), "dflow_bcd_phase")
+
+    def ceoBCD(self, bcd_times, on_sweep=None):
+        """python bcd.py:261-284.  on_sweep(w) is called after sweep w (the reference saves .npy there)."""
+        for w in range(1, bcd_times + 1):
+            _lib.check(_lib.lib().dflow_bcd_sweep(self._pp(), self.proposals.data_ptr(), self.lcosts.data_ptr(),
+                                                  self.nprop.data_ptr(), self.bestlabels.data_ptr(),
+                                                  self.ws.data_ptr(), self.ws_bytes, self._stream()),
+                       "dflow_bcd_sweep")
+            if on_sweep is not None:
+                on_sweep(w)
+
+    def vratiKonacniFlow(self, out=None):
+        """python bcd.py:90-95: (H,W,2) [dy,dx] (float32 device tensor; values are small integers)."""
+        out = self.flow if out is None else out
+        _lib.check(_lib.lib().dflow_labels_to_flow(self._pp(), self.proposals.data_ptr(), self.bestlabels.data_ptr(),
+                                                   out.data_ptr(), self._stream()), "dflow_labels_to_flow")
+        return out
+
+    def run(self, pic3, pic4, bcd_times):
+        """daisy i flann.py main (:406-422, without the file writes) followed by ceoBCD; returns the flow tensor."""
+        self.load_pair(pic3, pic4)
+        self.generisi()
+        self.nasumicni()
+        self.ceoBCD(bcd_times)
+        return self.vratiKonacniFlow()
+
+    # ------------------------------------------------------------------ reference dtypes on the host
+    def host_state(self):
+        """proposals int64 (H,W,150,2) / lcosts float64 / nprop, bestlabels int64, as the reference saves them
+        (daisy i flann.py:249-253)."""
+        L = self.p.maxnprop
+        packed = self.proposals[..., :L].cpu().numpy().view(np.uint32)
+        dy = (packed & 0xFFFF).astype(np.uint16).view(np.int16).astype(np.int64)
+        dx = (packed >> 16).astype(np.uint16).view(np.int16).astype(np.int64)
+        return dict(proposals=np.stack([dy, dx], axis=-1),
+                    lcosts=self.lcosts[..., :L].cpu().numpy().astype(np.float64),
+                    nprop=self.nprop.cpu().numpy().astype(np.int64),
+                    bestlabels=self.bestlabels.cpu().numpy().astype(np.int64))
+
+    def set_host_state(self, proposals, lcosts, nprop, bestlabels):
+        """Upload reference-dtype arrays (ucitajSvePodatkeDoBCD, python bcd.py:67-81)."""
+        L, LP = self.p.maxnprop, self.p.label_pitch
+        H, W = self.p.pich, self.p.picw
+        packed = np.full((H, W, LP), 0xFFFFFFFF, np.uint32)
+        packed[..., :L] = (proposals[..., 0].astype(np.int16).view(np.uint16).astype(np.uint32)
+                           | (proposals[..., 1].astype(np.int16).view(np.uint16).astype(np.uint32) << 16))
+        lc = np.full((H, W, LP), 1000.0, np.float32)
+        lc[..., :L] = lcosts.astype(np.float32)
+        self.proposals.copy_(torch.from_numpy(packed.view(np.int32)))
+        self.lcosts.copy_(torch.from_numpy(lc))
+        self.nprop.copy_(torch.from_numpy(nprop.astype(np.int32)))
+        self.bestlabels.copy_(torch.from_numpy(bestlabels.astype(np.int32)))
+
+
+def fb_consistency(fwd, bwd, tresh, p=None):
+    """postProcessing (postprocessing.py:123-135) on two (H,W,2) [dy,dx] float32 device tensors ->
+    (H,W,3) float32 [U,V,valid] device tensor."""
+    H, W, _ = fwd.shape
+    if p is None:
+        ch, cw = default_cells(H, W)
+        p = _lib.default_params(H, W, ch, cw)
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=fwd.device)
+    stream = C.c_void_p(torch.cuda.current_stream(fwd.device).cuda_stream)
+    _lib.check(_lib.lib().dflow_fb_consistency(C.byref(p), fwd.contiguous().data_ptr(), bwd.contiguous().data_ptr(),
+                                               float(tresh), out.data_ptr(), stream), "dflow_fb_consistency")
+    return out

@@ -302,7 +302,7 @@ void orc_knn_proposals(const orc_params *p, const float *d1, const float *d2,
                         const float *t = d2 + ((size_t)ty * W + tx) * ORC_DESC;
                         for (int k = 0; k < ORC_DESC; k++) diff[k] = fabsf(q[k] - t[k]);
                         float s = np_pairwise_sum68(diff);
-                        double c = (p->tphi < s) ? (double)p->tphi : (double)s;   /* min(tphi, s) :179 */
+                        double c = (s < p->tphi) ? (double)s : (double)p->tphi;   /* python min(tphi, s) :179 */
                         lcosts[pix * L + base + qq] = c;
                         if (c < mindists[pix]) { mindists[pix] = c; bestlabels[pix] = base + qq; } /* :181-184 */
                     }
@@ -406,7 +406,7 @@ void orc_neighbour_proposals(const orc_params *p, const float *d1, const float *
                     const float *q = d1 + pix * ORC_DESC, *t = d2 + tpix * ORC_DESC;
                     for (int k = 0; k < ORC_DESC; k++) diff[k] = q[k] - t[k];
                     float s = fabsf(np_pairwise_sum68(diff));                                   /* :228-229 (Q6) */
-                    lcosts[pix * L + np_] = (p->tphi < s) ? (double)p->tphi : (double)s;
+                    lcosts[pix * L + np_] = (s < p->tphi) ? (double)s : (double)p->tphi;   /* python min(tphi, s) */
                     nprop[pix] = np_ + 1; ngaussprop++;                                         /* :230-231 */
                 }
                 i++;                                                                            /* :233 */

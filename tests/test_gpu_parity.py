@@ -1,0 +1,184 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle and with the reference's golden vectors.
+Everything here needs a real MI355X: run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_NAMES, pkg
+
+pytestmark = pytest.mark.gpu
+
+# (H, W, cellh, cellw): exact tilings, ragged tilings (last cells absorb the remainder), more cells than the window
+GEOMS = [(40, 48, 5, 6), (36, 40, 9, 8), (45, 70, 7, 9), (96, 128, 12, 16), (64, 200, 10, 12)]
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch
+
+
+def make(H, W, ch, cw, seed=0):
+    return pkg("pipeline").DiscreteFlow(H, W, ch, cw, seed=seed)
+
+
+def oracle_params(O, df):
+    p = df.p
+    return O.make_params(p.pich, p.picw, p.cellh, p.cellw, seed=p.seed)
+
+
+@pytest.mark.parametrize("shape", [(40, 56), (97, 131), (436, 1024)])
+def test_daisy_bit_exact(torch_, oracle, synth, shape):
+    H, W = shape
+    img, _, _ = synth.make_pair(H, W, seed=H + W)
+    df = make(H, W, max(5, H // 8), max(5, W // 8))
+    got = df.izracunajDaisy(img).cpu().numpy()
+    want = oracle.daisy(img)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_stages_match_oracle(torch_, oracle, synth, geom):
+    """DAISY -> generisi -> nasumicni -> every BCD phase of 2 sweeps, each stage compared bit for bit."""
+    H, W, ch, cw = geom
+    O = oracle
+    img1, img2, _ = synth.make_pair(H, W, seed=H * W, amp_x=0.1 * W, amp_y=0.1 * H)
+    df = make(H, W, ch, cw, seed=1234 + H)
+    p = oracle_params(O, df)
+    df.load_pair(img1, img2)
+    d1, d2 = O.daisy(img1), O.daisy(img2)
+    assert np.array_equal(df.descrs1.cpu().numpy(), d1) and np.array_equal(df.descrs2.cpu().numpy(), d2)
+
+    df.generisi()
+    pr, lc, npr, bl = O.knn_proposals(p, d1, d2)
+    st = df.host_state()
+    assert np.array_equal(st["nprop"], npr)
+    assert np.array_equal(st["proposals"], pr), "bit-exact kNN candidate indices"
+    assert np.array_equal(st["lcosts"], lc)
+    assert np.array_equal(st["bestlabels"], bl)
+    assert np.array_equal(df.vratiKonacniFlow().cpu().numpy().astype(np.float64), O.labels_to_flow(p, pr, bl))
+
+    df.nasumicni()
+    O.neighbour_proposals(p, d1, d2, pr, lc, npr, bl)
+    st = df.host_state()
+    assert np.array_equal(st["nprop"], npr)
+    assert np.array_equal(st["proposals"], pr)
+    assert np.array_equal(st["lcosts"], lc)
+
+    for sweep in range(2):
+        for phase in range(4):
+            df.bcd_phase(phase)
+            O.bcd_phase(p, pr, lc, npr, bl, phase)
+            got = df.bestlabels.cpu().numpy()
+            assert np.array_equal(got, bl), "labels differ after sweep %d phase %d" % (sweep, phase)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+@pytest.mark.parametrize("backward", (0, 1))
+def test_hip_path_matches_reference_golden(torch_, golden, name, backward):
+    """HIP end to end against what the reference's own scripts produced (tests/golden), no oracle in between."""
+    g = golden(name)
+    df = make(int(g["H"]), int(g["W"]), int(g["cellh"]), int(g["cellw"]), seed=int(g["seed"]))
+    k = "b%d_" % backward
+    a, b = (g["img1"], g["img2"]) if backward == 0 else (g["img2"], g["img1"])
+    df.load_pair(a, b)
+    df.generisi()
+    assert np.array_equal(df.bestlabels.cpu().numpy(), g[k + "labels00"])
+    assert np.array_equal(df.vratiKonacniFlow().cpu().numpy(), g[k + "flow00"])
+    df.nasumicni()
+    st = df.host_state()
+    assert np.array_equal(st["nprop"], g[k + "nprop"])
+    assert np.array_equal(st["proposals"][:2], g[k + "proposals_rows"])
+    assert np.array_equal(st["lcosts"][:2], g[k + "lcosts_rows"])
+    for w in range(1, int(g["bcd_times"]) + 1):
+        df.ceoBCD(1)
+        assert np.array_equal(df.bestlabels.cpu().numpy(), g[k + "labels%02d" % w]), "sweep %d" % w
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_fb_consistency_matches_reference_golden(torch_, golden, name):
+    g = golden(name)
+    pl = pkg("pipeline")
+    flows = []
+    for backward in (0, 1):
+        df = make(int(g["H"]), int(g["W"]), int(g["cellh"]), int(g["cellw"]), seed=int(g["seed"]))
+        a, b = (g["img1"], g["img2"]) if backward == 0 else (g["img2"], g["img1"])
+        flows.append(df.run(a, b, int(g["bcd_times"])).clone())
+    for t in (1, 3):
+        got = pl.fb_consistency(flows[0], flows[1], t).cpu().numpy()
+        assert np.array_equal(got, g["sparse_t%d" % t])
+
+
+def test_bcd_from_uploaded_reference_state(torch_, oracle, synth):
+    """ucitajSvePodatkeDoBCD path: state produced on the CPU, uploaded in the reference's dtypes, swept on the GPU."""
+    H, W, ch, cw = 48, 64, 8, 8
+    O = oracle
+    img1, img2, _ = synth.make_pair(H, W, seed=77, amp_x=6, amp_y=4)
+    p = O.make_params(H, W, ch, cw, seed=5)
+    r = O.full_pass(p, img1, img2, 0)
+    df = make(H, W, ch, cw, seed=5)
+    df.set_host_state(r["proposals"], r["lcosts"], r["nprop"], r["bestlabels"])
+    bl = r["bestlabels"].copy()
+    for w in range(3):
+        df.ceoBCD(1)
+        O.bcd_sweep(p, r["proposals"], r["lcosts"], r["nprop"], bl)
+        assert np.array_equal(df.bestlabels.cpu().numpy(), bl)
+
+
+def test_full_size_sintel_properties_and_sampled_parity(torch_, oracle, synth):
+    """BASELINE config 2 geometry (1024x436, 64x27 cells, ragged last cell row).  The oracle cannot run the whole
+    kNN here in reasonable time, so: exact comparison on sampled (pixel, cell) searches, full comparison of the
+    neighbour stage and of one whole BCD sweep (the oracle does those in seconds), plus invariants."""
+    H, W = 436, 1024
+    O = oracle
+    img1, img2, gt = synth.make_pair(H, W, seed=2022)
+    df = make(H, W, seed=99)
+    p = oracle_params(O, df)
+    assert (p.cellh, p.cellw) == (27, 64)
+    df.load_pair(img1, img2)
+    d1, d2 = df.descrs1.cpu().numpy(), df.descrs2.cpu().numpy()
+    df.generisi()
+    st = df.host_state()
+    pr, lc, npr, bl = st["proposals"], st["lcosts"], st["nprop"], st["bestlabels"]
+    ncx, ncy = W // p.cellw, H // p.cellh
+    cy = np.minimum(np.arange(H) // p.cellh, ncy - 1); cx = np.minimum(np.arange(W) // p.cellw, ncx - 1)
+    wy = np.minimum(cy + 2, ncy - 1) - np.maximum(cy - 2, 0) + 1
+    wx = np.minimum(cx + 2, ncx - 1) - np.maximum(cx - 2, 0) + 1
+    assert np.array_equal(npr, 5 * wy[:, None] * wx[None, :])                 # nprop = 5 x window cells
+    assert np.all(bl < npr) and np.all(bl >= 0)
+    lab = np.arange(p.maxnprop)[None, None, :]
+    assert np.all(pr[lab[..., None].repeat(2, -1) >= npr[..., None, None]] == -1)   # -1 fill beyond nprop
+    assert np.all(lc[lab >= npr[..., None]] == 1000.0)
+    # every proposal lands inside the image and inside the +-2-cell window
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    ty = yy[..., None] + pr[..., 0]; tx = xx[..., None] + pr[..., 1]
+    valid = lab < npr[..., None]
+    assert np.all((ty >= 0) & (ty < H) & (tx >= 0) & (tx < W) | ~valid)
+    tcy = np.minimum(ty // p.cellh, ncy - 1); tcx = np.minimum(tx // p.cellw, ncx - 1)
+    assert np.all((np.abs(tcy - cy[:, None, None]) <= 2) & (np.abs(tcx - cx[None, :, None]) <= 2) | ~valid)
+    # WTA label = first minimum of the costs
+    assert np.array_equal(bl, np.argmin(np.where(valid, lc, np.inf), axis=-1))
+    # sampled exact searches (bit-exact indices): pixel -> every cell of its window
+    rng = np.random.default_rng(1)
+    for _ in range(24):
+        y, x = int(rng.integers(H)), int(rng.integers(W))
+        slot = 0
+        for ci in range(max(0, cx[x] - 2), min(ncx - 1, cx[x] + 2) + 1):
+            for cj in range(max(0, cy[y] - 2), min(ncy - 1, cy[y] + 2) + 1):
+                idx, _ = O.knn_cell(p, d1[y, x], d2, ci, cj)
+                cwid = (W if ci == ncx - 1 else (ci + 1) * p.cellw) - ci * p.cellw
+                want = np.stack([cj * p.cellh + idx // cwid - y, ci * p.cellw + idx % cwid - x], -1)
+                assert np.array_equal(pr[y, x, slot:slot + 5], want), (y, x, ci, cj)
+                slot += 5
+    # neighbour stage and one full BCD sweep against the oracle on the GPU's own state
+    df.nasumicni()
+    O.neighbour_proposals(p, d1, d2, pr, lc, npr, bl)
+    st = df.host_state()
+    assert np.array_equal(st["nprop"], npr) and np.array_equal(st["proposals"], pr) and np.array_equal(st["lcosts"], lc)
+    df.ceoBCD(1)
+    O.bcd_sweep(p, pr, lc, npr, bl)
+    assert np.array_equal(df.bestlabels.cpu().numpy(), bl)
+    # flow quality sanity: the discrete labels sit near the synthetic ground truth
+    flow = df.vratiKonacniFlow().cpu().numpy()
+    epe = np.sqrt(((flow - gt) ** 2).sum(-1))
+    assert np.median(epe) < 2.0
