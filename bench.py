@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the dense discrete optical-flow hot path on MI355X.
+
+Metric (BASELINE.json): Mpix/s of flow at 1024x436 (Sintel shape), bcd_times=4.
+A "step" is one full pass of the hot path over one synthetic image pair that is already resident in HBM:
+DAISY x2 -> per-cell exact 5-NN proposals -> neighbour proposals -> 4 BCD sweeps -> labels->flow.
+N > 1: one process per GPU (torch.distributed over RCCL); every rank processes its own pairs (weak scaling,
+no data-path collective) and the flow fields are gathered on rank 0 over xGMI after every step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "lk-s-2022-estimacija-pokreta_amd"
+
+H, W, BCD_TIMES = 436, 1024, 4
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: FP32 vector = FP32 matrix (f32-in MFMA) peak
+
+
+def knn_pairs(pich, picw, cellh, cellw, window=2):
+    """Number of (image-1 pixel, image-2 candidate) distance evaluations of one pass."""
+    ncx, ncy = picw // cellw, pich // cellh
+    wx = [(picw if c == ncx - 1 else (c + 1) * cellw) - c * cellw for c in range(ncx)]
+    wy = [(pich if c == ncy - 1 else (c + 1) * cellh) - c * cellh for c in range(ncy)]
+    sx = sum(wx[ci] * sum(wx[max(0, ci - window):ci + window + 1]) for ci in range(ncx))
+    sy = sum(wy[cj] * sum(wy[max(0, cj - window):cj + window + 1]) for cj in range(ncy))
+    return sx * sy
+
+
+def cpu_baseline(synth):
+    """The CPU oracle (a C port of the reference path, single thread) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    O.build()
+    h, w = 109, 256                                  # 1/16 of the frame area, same 27x64 cells, same bcd_times
+    img1, img2, _ = synth.make_pair(h, w, seed=4242, amp_x=40.0, amp_y=20.0)
+    p = O.make_params(h, w, 27, 64, seed=1)
+    t0 = time.perf_counter()
+    O.full_pass(p, img1, img2, BCD_TIMES)
+    dt = time.perf_counter() - t0
+    return {"value": h * w / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": "%dx%d crop-sized synthetic pair (1/16 frame), cells 27x64, bcd_times=%d, %.1f s; "
+                      "C restatement of daisy i flann.py + python bcd.py (oracle/), exact kNN instead of FLANN"
+                      % (w, h, BCD_TIMES, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    synth = importlib.import_module(PKG + ".synth")
+    pipeline = importlib.import_module(PKG + ".pipeline")
+    sharding = importlib.import_module(PKG + ".sharding")
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cellh, cellw = pipeline.default_cells(H, W)
+    df = pipeline.DiscreteFlow(H, W, cellh, cellw, device=dev, seed=rank)
+    # two distinct synthetic pairs per rank, resident in HBM before the timed region
+    pairs = []
+    for j in range(2):
+        img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(2 * rank + j, 0))
+        pairs.append((torch.from_numpy(img1).to(dev), torch.from_numpy(img2).to(dev)))
+    gather_buf = sharding.make_gather_buffers(df.flow, world, rank) if world > 1 else None
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    knn_events = []
+
+    def step(i, timed):
+        a, b = pairs[i % 2]
+        df.load_pair(a, b)
+        if timed:
+            e0, e1 = ev(), ev()
+            e0.record()
+        df.generisi()
+        if timed:
+            e1.record()
+            knn_events.append((e0, e1))
+        df.nasumicni()
+        df.ceoBCD(BCD_TIMES)
+        flow = df.vratiKonacniFlow()
+        if world > 1:
+            sharding.gather_flows(flow, gather_buf, rank)
+        return flow
+
+    for i in range(args.warmup):
+        step(i, False)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
+        pairs_n = knn_pairs(H, W, cellh, cellw)
+        flops = pairs_n * 2 * 68                      # 136 flop per descriptor pair
+        achieved = flops / (knn_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mpix/s flow (1024x436, bcd_times=4)",
+            "value": world * args.steps * H * W / dt / 1e6,
+            "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "single 1024x436 Sintel-shape pair per step per GPU, forward only, bcd_times=4 "
+                                   "(BASELINE.json configs[1]); cells 64x27, 150 labels/px",
+                       "pairs_per_step_per_gpu": 1, "parallelism": "one pass per GPU, flow fields gathered on rank 0"},
+            "roofline": {"bound": "mfma", "kernel": "knn_exact_kernel", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "launch_ms": knn_ms, "algorithmic_flops_per_launch": flops},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(synth)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

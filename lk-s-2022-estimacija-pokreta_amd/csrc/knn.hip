@@ -94,8 +94,10 @@ __global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, co
                         e = q[4 * k + 3] - v.w; acc = __fmaf_rn(e, e, acc);
                     }
                     if (acc < d4) {   // insert keeping ascending order; strict '<' leaves equal distances in index order
-                        float cd = acc; int cidx = (yy - cy0) * ccw + xx;
-#define CSWAP(D, I) if (cd < D) { float td = D; int ti = I; D = cd; I = cidx; cd = td; cidx = ti; }
+                        // once the new entry has found its place every later entry shifts down unconditionally
+                        // (a displaced entry must stay in front of an equal one that followed it)
+                        float cd = acc; int cidx = (yy - cy0) * ccw + xx; bool sh = false;
+#define CSWAP(D, I) if (sh || cd < D) { float td = D; int ti = I; D = cd; I = cidx; cd = td; cidx = ti; sh = true; }
                         CSWAP(d0, i0) CSWAP(d1, i1) CSWAP(d2, i2) CSWAP(d3, i3) CSWAP(d4, i4)
 #undef CSWAP
                     }

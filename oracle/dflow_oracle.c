@@ -13,7 +13,7 @@
  *     PARITY UNPINNED -- those libraries are not installed and the reference holds no vectors for them; the
  *     definitions here are the spec for this build (DESIGN.md "Oracle").
  *
- * Build: gcc -O2 -ffp-contract=off -mfma -fPIC -shared (see oracle/Makefile).  -ffp-contract=off matters:
+ * Build: gcc -O3 -ffp-contract=off -mavx2 -mfma -fPIC -shared (see oracle/Makefile).  -ffp-contract=off matters:
  * every float op below is a single IEEE operation unless it is an explicit fmaf().
  */
 #include <math.h>
@@ -263,14 +263,31 @@ void orc_knn_points(const float *q, const float *pts, int n, int K, int32_t *idx
     for (int r = 0; r < n; r++) m = topk_insert(K, m, dist, idx, knn_dist(q, pts + (size_t)r * ORC_DESC), r);
 }
 
+/* eight independent fmaf chains at once (same per-candidate arithmetic as knn_dist, just interleaved so the
+ * CPU pipelines them); rows are consecutive 68-float descriptors */
+static inline void knn_dist8(const float *a, const float *rows, float *out)
+{
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < ORC_DESC; k++)
+        for (int c = 0; c < 8; c++) { float d = a[k] - rows[c * ORC_DESC + k]; acc[c] = fmaf(d, d, acc[c]); }
+    for (int c = 0; c < 8; c++) out[c] = acc[c];
+}
+
 /* exact 5-NN of query q among the points of cell (ci,cj) of image 2; idx = in-cell row-major index */
 void orc_knn_cell(const orc_params *p, const float *q, const float *d2, int ci, int cj, int32_t *idx, float *dist)
 {
     int K = p->knn, x0 = cell_x0(p, ci), x1 = cell_x1(p, ci), y0 = cell_y0(p, cj), y1 = cell_y1(p, cj);
     int cw = x1 - x0, n = 0;
-    for (int yy = y0; yy < y1; yy++)
-        for (int xx = x0; xx < x1; xx++)
-            n = topk_insert(K, n, dist, idx, knn_dist(q, d2 + ((size_t)yy * p->picw + xx) * ORC_DESC), (yy - y0) * cw + (xx - x0));
+    float d8[8];
+    for (int yy = y0; yy < y1; yy++) {
+        const float *row = d2 + ((size_t)yy * p->picw + x0) * ORC_DESC;
+        int xx = 0;
+        for (; xx + 8 <= cw; xx += 8) {
+            knn_dist8(q, row + (size_t)xx * ORC_DESC, d8);
+            for (int c = 0; c < 8; c++) n = topk_insert(K, n, dist, idx, d8[c], (yy - y0) * cw + xx + c);
+        }
+        for (; xx < cw; xx++) n = topk_insert(K, n, dist, idx, knn_dist(q, row + (size_t)xx * ORC_DESC), (yy - y0) * cw + xx);
+    }
 }
 
 void orc_knn_proposals(const orc_params *p, const float *d1, const float *d2,
