@@ -2,6 +2,7 @@
 // accounting and dispatch to the per-stage launchers.  No torch types, no allocation, no synchronisation.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "dflow_common.h"
 
@@ -62,8 +63,9 @@ void dflow_default_params(dflow_params *p, int32_t pich, int32_t picw, int32_t c
 size_t dflow_workspace_bytes(const dflow_params *p)
 {
     if (dflow_check_params(p) != DFLOW_OK) return 0;
-    size_t a = daisy_ws_bytes(p), b = bcd_ws_bytes(p);
-    return (a > b ? a : b) + 256;
+    size_t a = daisy_ws_bytes(p), b = bcd_ws_bytes(p), c = knn_mfma_supported(p) ? knn_mfma_ws_bytes(p) : 0;
+    size_t m = a > b ? a : b;
+    return (m > c ? m : c) + 256;
 }
 
 #define CHECK_PTR(x) do { if (!(x)) return dflow_set_error(DFLOW_EINVAL, "%s: %s is NULL", __func__, #x); } while (0)
@@ -80,10 +82,14 @@ int dflow_daisy(const dflow_params *p, const uint8_t *d_bgr, float *d_descr, voi
 int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,
                         float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream)
 {
-    (void)d_ws; (void)ws_bytes;
     int rc = dflow_check_params(p); if (rc) return rc;
     CHECK_PTR(d_descr1); CHECK_PTR(d_descr2); CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels);
-    return launch_knn(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, (hipStream_t)stream);
+    // DFLOW_KNN=exact selects the brute-force VALU kernel (same results; used to cross-check the MFMA path)
+    const char *mode = getenv("DFLOW_KNN");
+    if ((mode && strcmp(mode, "exact") == 0) || !knn_mfma_supported(p))
+        return launch_knn(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, (hipStream_t)stream);
+    CHECK_WS(knn_mfma_ws_bytes(p));
+    return launch_knn_mfma(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, d_ws, (hipStream_t)stream);
 }
 
 int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,

@@ -56,6 +56,30 @@ __device__ static inline float np_pairwise_sum68(const float *a)
     return res;
 }
 
+// sum_k |a[k]-b[k]| in numpy's float32 pairwise order (np.sum(np.absolute(..)), daisy i flann.py:179-180).
+// Cold path (5 winners per cell): both rows are re-read from memory in a rolled loop so that the hot search
+// loop keeps its register budget.
+__device__ __noinline__ static float l1_cost_np(const float *__restrict__ a, const float *__restrict__ b)
+{
+    const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
+    float r[8];
+    {
+        float4 u0 = a4[0], u1 = a4[1], v0 = b4[0], v1 = b4[1];
+        r[0] = fabsf(u0.x - v0.x); r[1] = fabsf(u0.y - v0.y); r[2] = fabsf(u0.z - v0.z); r[3] = fabsf(u0.w - v0.w);
+        r[4] = fabsf(u1.x - v1.x); r[5] = fabsf(u1.y - v1.y); r[6] = fabsf(u1.z - v1.z); r[7] = fabsf(u1.w - v1.w);
+    }
+#pragma unroll 1
+    for (int i = 2; i < 16; i += 2) {
+        float4 u0 = a4[i], u1 = a4[i + 1], v0 = b4[i], v1 = b4[i + 1];
+        r[0] = r[0] + fabsf(u0.x - v0.x); r[1] = r[1] + fabsf(u0.y - v0.y); r[2] = r[2] + fabsf(u0.z - v0.z); r[3] = r[3] + fabsf(u0.w - v0.w);
+        r[4] = r[4] + fabsf(u1.x - v1.x); r[5] = r[5] + fabsf(u1.y - v1.y); r[6] = r[6] + fabsf(u1.z - v1.z); r[7] = r[7] + fabsf(u1.w - v1.w);
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    float4 u = a4[16], v = b4[16];
+    res = res + fabsf(u.x - v.x); res = res + fabsf(u.y - v.y); res = res + fabsf(u.z - v.z); res = res + fabsf(u.w - v.w);
+    return res;
+}
+
 // error plumbing (abi.hip)
 int dflow_set_error(int code, const char *fmt, ...);
 int dflow_check_launch(const char *what);
@@ -66,6 +90,10 @@ int launch_daisy(const dflow_params *p, const uint8_t *bgr, float *descr, void *
 size_t daisy_ws_bytes(const dflow_params *p);
 int launch_knn(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
                int32_t *nprop, int32_t *bestlabels, hipStream_t s);
+int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+                    int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s);
+size_t knn_mfma_ws_bytes(const dflow_params *p);
+bool knn_mfma_supported(const dflow_params *p);
 int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
                      int32_t *nprop, const int32_t *bestlabels, hipStream_t s);
 int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop,

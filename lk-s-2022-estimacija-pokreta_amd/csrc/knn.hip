@@ -1,14 +1,15 @@
-// K3/K4 knn_cells (exact path): generisi, daisy i flann.py:157-189, with the FLANN search (:171-172) replaced by
+// K3/K4 knn_cells, exact VALU path: generisi, daisy i flann.py:157-189, with the FLANN search (:171-172) replaced by
 // the build's canonical exact 5-NN: squared L2 as a sequential fmaf chain over k = 0..67, ties to the lower
 // in-cell index, results in ascending (distance, index) order.
 //
-// One thread = one image-1 pixel (query); its 68-float descriptor stays in VGPRs.  A workgroup = 256 queries
-// of ONE cell of image 1, so all its lanes share the same window of image-2 cells and walk the candidate
-// points in lock-step: the candidate's descriptor address is wave-uniform, so it is fetched through the
-// scalar cache (s_load) and used as SGPR operands -- no LDS traffic, no barriers.  Per (query, candidate):
-// 68 x (v_sub_f32, v_fma_f32).  Cells are visited in the reference's order (ci outer, cj inner, Q2) so slot
-// numbers, truncated-L1 costs (numpy pairwise order, Q3) and the running WTA label (strict '<', Q4) come
-// out as in the reference.
+// This file holds (a) the brute-force kernel (DFLOW_KNN=exact, and the fallback for geometries the MFMA path does
+// not cover) and (b) the fix-up kernel that re-does, exactly, the few (query wave, candidate cell) pairs the MFMA
+// path hands back (event-list overflow, or descriptors outside the f16 range).
+//
+// One thread = one image-1 pixel (query); its 68-float descriptor stays in VGPRs.  All lanes of a wave belong to
+// ONE image-1 cell, share the same window of image-2 cells and walk the candidate points in lock-step: the
+// candidate's address is wave-uniform, so it is fetched through the scalar cache (s_load_dwordx16) and used as
+// SGPR operands -- no LDS traffic, no barriers.  Per (query, candidate): 68 x (v_sub_f32, v_fma_f32).
 #include "dflow_common.h"
 
 #define KNN_THREADS 256
@@ -19,32 +20,75 @@ struct KnnArgs {
     float tphi;
 };
 
-// sum_k |a[k]-b[k]| in numpy's float32 pairwise order (np.sum(np.absolute(..)), daisy i flann.py:179-180).
-// Cold path (5 winners per cell): both rows are re-read from memory in a rolled loop so that the hot search
-// loop keeps its register budget.
-__device__ __noinline__ static float l1_cost_np(const float *__restrict__ a, const float *__restrict__ b)
+struct Top5 {
+    float d0, d1, d2, d3, d4;
+    int i0, i1, i2, i3, i4;
+};
+
+// exact search of one candidate cell for the query held in q[]; gd2 must be a __restrict__ kernel argument
+__device__ static inline void search_cell_exact(const float (&q)[DFLOW_DESC], const float *__restrict__ gd2, const Geom &g,
+                                                int ci, int cj, Top5 &t)
 {
-    const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
-    float r[8];
-    {
-        float4 u0 = a4[0], u1 = a4[1], v0 = b4[0], v1 = b4[1];
-        r[0] = fabsf(u0.x - v0.x); r[1] = fabsf(u0.y - v0.y); r[2] = fabsf(u0.z - v0.z); r[3] = fabsf(u0.w - v0.w);
-        r[4] = fabsf(u1.x - v1.x); r[5] = fabsf(u1.y - v1.y); r[6] = fabsf(u1.z - v1.z); r[7] = fabsf(u1.w - v1.w);
+    const int cx0 = g.x0(ci), cx1 = g.x1(ci), cy0 = g.y0(cj), cy1 = g.y1(cj), ccw = cx1 - cx0;
+    t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
+    t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
+    for (int yy = cy0; yy < cy1; yy++) {
+        const float4 *__restrict__ row = reinterpret_cast<const float4 *>(gd2 + ((size_t)yy * g.W + cx0) * DFLOW_DESC);
+        for (int xx = 0; xx < ccw; xx++) {
+            const float4 *__restrict__ c = row + xx * (DFLOW_DESC / 4);   // wave-uniform address
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < DFLOW_DESC / 4; k++) {
+                float4 v = c[k];
+                float e;
+                e = q[4 * k] - v.x; acc = __fmaf_rn(e, e, acc);
+                e = q[4 * k + 1] - v.y; acc = __fmaf_rn(e, e, acc);
+                e = q[4 * k + 2] - v.z; acc = __fmaf_rn(e, e, acc);
+                e = q[4 * k + 3] - v.w; acc = __fmaf_rn(e, e, acc);
+            }
+            if (acc < t.d4) {
+                // insert keeping ascending order; strict '<' leaves equal distances in index order; once the new
+                // entry has found its place every later entry shifts down unconditionally (a displaced entry must
+                // stay in front of an equal one that followed it)
+                float cd = acc; int cidx = (yy - cy0) * ccw + xx; bool sh = false;
+#define CSWAP(D, I) if (sh || cd < D) { float td = D; int ti = I; D = cd; I = cidx; cd = td; cidx = ti; sh = true; }
+                CSWAP(t.d0, t.i0) CSWAP(t.d1, t.i1) CSWAP(t.d2, t.i2) CSWAP(t.d3, t.i3) CSWAP(t.d4, t.i4)
+#undef CSWAP
+            }
+        }
     }
-#pragma unroll 1
-    for (int i = 2; i < 16; i += 2) {
-        float4 u0 = a4[i], u1 = a4[i + 1], v0 = b4[i], v1 = b4[i + 1];
-        r[0] = r[0] + fabsf(u0.x - v0.x); r[1] = r[1] + fabsf(u0.y - v0.y); r[2] = r[2] + fabsf(u0.z - v0.z); r[3] = r[3] + fabsf(u0.w - v0.w);
-        r[4] = r[4] + fabsf(u1.x - v1.x); r[5] = r[5] + fabsf(u1.y - v1.y); r[6] = r[6] + fabsf(u1.z - v1.z); r[7] = r[7] + fabsf(u1.w - v1.w);
-    }
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    float4 u = a4[16], v = b4[16];
-    res = res + fabsf(u.x - v.x); res = res + fabsf(u.y - v.y); res = res + fabsf(u.z - v.z); res = res + fabsf(u.w - v.w);
-    return res;
 }
 
-// d2 is only ever read and never aliases the outputs: with __restrict__ kernel arguments the compiler can prove
-// it and turns the wave-uniform candidate loads into scalar loads.
+// daisy i flann.py:174-180: proposals [dy,dx] and truncated L1 costs of the 5 winners of one cell
+__device__ static inline void emit_cell(const Top5 &t, const Geom &g, int ci, int cj, size_t pix, int qy, int qx, int slot,
+                                        int LP, float tphi, bool active, const float *__restrict__ gd1,
+                                        const float *__restrict__ gd2, uint32_t *__restrict__ gproposals,
+                                        float *__restrict__ glcosts, float *cost_out)
+{
+    const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0;
+    const int idx[5] = {t.i0, t.i1, t.i2, t.i3, t.i4};
+#pragma unroll
+    for (int qq = 0; qq < 5; qq++) {
+        const int ty = cy0 + idx[qq] / ccw, tx = cx0 + idx[qq] % ccw;
+        const float s = l1_cost_np(gd1 + pix * DFLOW_DESC, gd2 + ((size_t)ty * g.W + tx) * DFLOW_DESC);
+        const float c = s < tphi ? s : tphi;   // python min(tphi, s)
+        if (active) {
+            gproposals[pix * LP + slot + qq] = pack_flow(ty - qy, tx - qx);
+            glcosts[pix * LP + slot + qq] = c;
+        }
+        cost_out[qq] = c;
+    }
+}
+
+__device__ static inline void load_query(float (&q)[DFLOW_DESC], const float *__restrict__ gd1, size_t pix)
+{
+    const float4 *s = reinterpret_cast<const float4 *>(gd1 + pix * DFLOW_DESC);
+#pragma unroll
+    for (int k = 0; k < DFLOW_DESC / 4; k++) { float4 v = s[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
+}
+
+// gd2 is only ever read and never aliases the outputs: with __restrict__ kernel arguments the compiler can prove it
+// and turns the wave-uniform candidate loads into scalar loads.
 __global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, const float *__restrict__ gd1,
                                                                    const float *__restrict__ gd2,
                                                                    uint32_t *__restrict__ gproposals,
@@ -62,66 +106,74 @@ __global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, co
     if (!active) qi = qnpts - 1;
     const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
     const size_t pix = (size_t)qy * g.W + qx;
-
     float q[DFLOW_DESC];
-    {
-        const float4 *s = reinterpret_cast<const float4 *>(gd1 + pix * DFLOW_DESC);
-#pragma unroll
-        for (int k = 0; k < DFLOW_DESC / 4; k++) { float4 v = s[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
-    }
+    load_query(q, gd1, pix);
     const int cimin = max(0, qci - g.win), cimax = min(g.ncx - 1, qci + g.win);
     const int cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
     float mind = 1000.0f;   // mindists, daisy i flann.py:93
     int bestl = 0, slot = 0;
-
-    for (int ci = cimin; ci <= cimax; ci++)
+    for (int ci = cimin; ci <= cimax; ci++)          // ci outer, cj inner (Q2)
         for (int cj = cjmin; cj <= cjmax; cj++) {
-            const int cx0 = g.x0(ci), cx1 = g.x1(ci), cy0 = g.y0(cj), cy1 = g.y1(cj), ccw = cx1 - cx0;
-            float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY, d3 = INFINITY, d4 = INFINITY;
-            int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0;
-            for (int yy = cy0; yy < cy1; yy++) {
-                const float4 *__restrict__ row = reinterpret_cast<const float4 *>(gd2 + ((size_t)yy * g.W + cx0) * DFLOW_DESC);
-                for (int xx = 0; xx < ccw; xx++) {
-                    const float4 *__restrict__ t = row + xx * (DFLOW_DESC / 4);   // wave-uniform address
-                    float acc = 0.0f;
+            Top5 t;
+            search_cell_exact(q, gd2, g, ci, cj, t);
+            float c[5];
+            emit_cell(t, g, ci, cj, pix, qy, qx, slot, a.LP, a.tphi, active, gd1, gd2, gproposals, glcosts, c);
 #pragma unroll
-                    for (int k = 0; k < DFLOW_DESC / 4; k++) {
-                        float4 v = t[k];
-                        float e;
-                        e = q[4 * k] - v.x; acc = __fmaf_rn(e, e, acc);
-                        e = q[4 * k + 1] - v.y; acc = __fmaf_rn(e, e, acc);
-                        e = q[4 * k + 2] - v.z; acc = __fmaf_rn(e, e, acc);
-                        e = q[4 * k + 3] - v.w; acc = __fmaf_rn(e, e, acc);
-                    }
-                    if (acc < d4) {   // insert keeping ascending order; strict '<' leaves equal distances in index order
-                        // once the new entry has found its place every later entry shifts down unconditionally
-                        // (a displaced entry must stay in front of an equal one that followed it)
-                        float cd = acc; int cidx = (yy - cy0) * ccw + xx; bool sh = false;
-#define CSWAP(D, I) if (sh || cd < D) { float td = D; int ti = I; D = cd; I = cidx; cd = td; cidx = ti; sh = true; }
-                        CSWAP(d0, i0) CSWAP(d1, i1) CSWAP(d2, i2) CSWAP(d3, i3) CSWAP(d4, i4)
-#undef CSWAP
-                    }
-                }
-            }
-            // daisy i flann.py:174-189: proposals [dy,dx], truncated L1 cost, WTA update, nprop += 5
-            const int idx[5] = {i0, i1, i2, i3, i4};
-#pragma unroll
-            for (int qq = 0; qq < 5; qq++) {
-                const int ty = cy0 + idx[qq] / ccw, tx = cx0 + idx[qq] % ccw;
-                const float s = l1_cost_np(gd1 + pix * DFLOW_DESC, gd2 + ((size_t)ty * g.W + tx) * DFLOW_DESC);
-                const float c = s < a.tphi ? s : a.tphi;   // python min(tphi, s)
-                if (active) {
-                    gproposals[pix * a.LP + slot + qq] = pack_flow(ty - qy, tx - qx);
-                    glcosts[pix * a.LP + slot + qq] = c;
-                }
-                if (c < mind) { mind = c; bestl = slot + qq; }
-            }
-            slot += 5;
+            for (int qq = 0; qq < 5; qq++)
+                if (c[qq] < mind) { mind = c[qq]; bestl = slot + qq; }   // WTA, strict '<' (:181-184)
+            slot += 5;                                                     // nprop += 5 (:189)
         }
     if (active) {
         gnprop[pix] = slot;
         gbestlabels[pix] = bestl;
         for (int s = slot; s < a.LP; s++) { gproposals[pix * a.LP + s] = DFLOW_FILL_PROPOSAL; glcosts[pix * a.LP + s] = DFLOW_FILL_COST; }
+    }
+}
+
+// Fix-up for the MFMA path.  Work item = (query cell, first query index, 64 queries, candidate cell).  Items come
+// from the overflow list, or -- if the prep kernel flagged out-of-range descriptors or the list itself overflowed --
+// every item of the pass is enumerated.  Blocks of one wave walk the items grid-stride.
+__global__ void __launch_bounds__(64, 4) knn_fix_kernel(KnnArgs a, const float *__restrict__ gd1, const float *__restrict__ gd2,
+                                                        uint32_t *__restrict__ gproposals, float *__restrict__ glcosts,
+                                                        const int *__restrict__ ovf_count, const int4 *__restrict__ ovf_list,
+                                                        int ovf_cap, const int *__restrict__ flags, int qwaves)
+{
+    const Geom g = a.g;
+    const int win = 2 * g.win + 1;
+    const int nov = *ovf_count;
+    const bool all = (*flags != 0) || nov > ovf_cap;
+    const int total = all ? g.ncx * g.ncy * qwaves * win * win : nov;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        int qcell, qstart, ci, cj;
+        if (all) {
+            int b = item;
+            const int wslot = b % (win * win); b /= win * win;
+            qstart = (b % qwaves) * 64; qcell = b / qwaves;
+            const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
+            const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
+            const int ncyw = cjmax - cjmin + 1;
+            ci = cimin + wslot / ncyw; cj = cjmin + wslot % ncyw;
+            if (ci > min(g.ncx - 1, qci + g.win)) continue;
+        } else {
+            int4 e = ovf_list[item];
+            qcell = e.x; qstart = e.y; ci = e.z; cj = e.w;
+        }
+        const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
+        const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
+        if (qstart >= qnpts) continue;
+        int qi = qstart + threadIdx.x;
+        const bool active = qi < qnpts;
+        if (!active) qi = qnpts - 1;
+        const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
+        const size_t pix = (size_t)qy * g.W + qx;
+        const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
+        const int slot = 5 * ((ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin));
+        float q[DFLOW_DESC];
+        load_query(q, gd1, pix);
+        Top5 t;
+        search_cell_exact(q, gd2, g, ci, cj, t);
+        float c[5];
+        emit_cell(t, g, ci, cj, pix, qy, qx, slot, a.LP, a.tphi, active, gd1, gd2, gproposals, glcosts, c);
     }
 }
 
@@ -136,4 +188,17 @@ int launch_knn(const dflow_params *p, const float *d1, const float *d2, uint32_t
     int nblocks = a.g.ncx * a.g.ncy * a.chunks;
     hipLaunchKernelGGL(knn_exact_kernel, dim3(nblocks), dim3(KNN_THREADS), 0, s, a, d1, d2, proposals, lcosts, nprop, bestlabels);
     return dflow_check_launch("knn_exact_kernel");
+}
+
+int launch_knn_fix(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+                   const int *ovf_count, const int4 *ovf_list, int ovf_cap, const int *flags, hipStream_t s)
+{
+    KnnArgs a;
+    a.g = make_geom(p);
+    a.LP = p->label_pitch; a.tphi = p->tphi; a.chunks = 0;
+    int maxpts = (a.g.x1(a.g.ncx - 1) - a.g.x0(a.g.ncx - 1)) * (a.g.y1(a.g.ncy - 1) - a.g.y0(a.g.ncy - 1));
+    int qwaves = (maxpts + 63) / 64;
+    hipLaunchKernelGGL(knn_fix_kernel, dim3(4096), dim3(64), 0, s, a, d1, d2, proposals, lcosts, ovf_count, ovf_list, ovf_cap,
+                       flags, qwaves);
+    return dflow_check_launch("knn_fix_kernel");
 }
