@@ -4,24 +4,31 @@
 // bit for bit -- but the 1.7e10 descriptor pairs of a Sintel pass are screened by f16 MFMA instead of being
 // evaluated one by one:
 //
-//   prep      both images -> rows of 80 f16: 68 scaled descriptor values (alpha = 64), then for image 2 three f16
-//             pieces of h = 0.5*|c~|^2 (for image 1: -1,-1,-1), zero padding; |q~|, |c~| and the per-cell max |c~|.
-//             One MFMA chain then yields t(q,c) = q~.c~ - 0.5|c~|^2 = 0.5(|q~|^2 - d^2) up to a rigorous error
-//             eps(q, cell) = 1.25 * 2^-10 * (|q~| C + C^2/2) (+ tiny absolute term), C = max |c~| in the cell
-//             (f16 rounding of both operands, f32 accumulation, rounding of the canonical distance).
-//   pass 1    t for every (query, candidate) of a (256-query block, candidate cell); every lane keeps the 5 largest
-//             maxima of its 16-value tile columns -> a lower bound a5 of the 5th largest t of its query.
-//   pass 2    t again; every candidate with t >= a5 - 2 eps is an "event" -- only those can be among the exact 5 NN.
-//   resolve   events (about 18 of 1728 candidates per query) get the canonical float32 distance (sequential fmaf
-//             chain) and are merged into the query's exact top-5 by cascaded 64-bit LDS atomic minima on
-//             (distance bits, index) keys, which is exactly the canonical (distance, index) order.
-//   emit      proposals [dy,dx] and truncated L1 costs (numpy order) into the cell's 5 slots (Q1-Q3);
-//             knn_finalize_kernel then sets nprop, the WTA label (first minimum, Q4) and the fills.
+//   prep      both images -> rows of 80 f16: 68 scaled descriptor values x~ = f16(64 x) (must be >= 0, as DAISY's
+//             are), then for image 2 two f16 triples h-, h+ of h = 0.5*|64 c|^2 (slightly enlarged / reduced, see
+//             below), for image 1 the matching -1 / 0 selectors, zero padding; and |q~| per query.
+//             With G = q~.c~ (exact products, f32 accumulation) the MFMA value t = G - h equals
+//             tau = 0.5(|64 q|^2 - 64^2 d^2) up to eps(q,c) = 1.25 * 2^-10 * G + 2^-15 h + O(2^-17 |q~|^2): f16
+//             rounding of both operands (relative 2^-11 each, G has only non-negative terms), f32 accumulation,
+//             rounding of h and of the canonical float32 distance.  The bound is per candidate: it is folded into
+//             the MFMA by scaling h (h- = h (1+2^-14)/(1-k), h+ = h (1-2^-14)/(1+k), k = 1.25*2^-10):
+//   screen    (knn_screen_kernel) pass 1: w = G - h- for every (query, candidate) of a (256-query block, candidate
+//             cell); (1-k) w <= tau.  Every lane keeps the 5 largest maxima of its 16-value tile columns -> a5, and
+//             (1-k) a5 is a lower bound of the 5th largest tau of the query.  pass 2: v = G - h+; (1+k) v >= tau.
+//             Only candidates with (1+k) v >= (1-k) a5 - s_q can be among the exact 5 NN: these "events" (a 16-bit
+//             row mask per lane and tile) go to per-lane lists in the workspace.
+//   resolve   (knn_resolve_kernel) one wave per event list: canonical float32 distance (sequential fmaf chain, with
+//             early exit once the partial sum exceeds the lane's 5th best) and truncated L1 cost (numpy order) of
+//             every event, exact (distance, index) top-5 in registers, proposals [dy,dx] and costs into the cell's
+//             5 slots (Q1-Q3).
+//   fix       lists that overflowed (or a pass with descriptors outside the f16 range / negative values) are redone
+//             by the exact brute-force search (knn.hip).  finalize sets nprop, the WTA label (first minimum, Q4)
+//             and the fills.
 //
 // MFMA layout (v_mfma_f32_32x32x16_f16): A = candidates (rows), B = queries (columns): lane l holds
 // A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31]; D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5).
 // A workgroup is 4 waves x 64 queries (2 column groups) of one image-1 cell; candidates stream through LDS in
-// chunks of 96 rows (176-byte pitch: conflict-free ds_read_b128), double buffered.
+// chunks of 96 rows (176-byte pitch: conflict-free ds_read_b128), double buffered by global_load_lds DMA.
 #include "dflow_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -34,26 +41,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KM_QPW 64               // queries per wave: 2 column groups of 32
 #define KM_QPB (KM_WAVES * KM_QPW)
 #define KM_CHUNK 96             // candidates per LDS chunk (3 tiles of 32)
+#define KM_ABUF (17 * 1024)      // bytes per staged chunk buffer (96 rows x 176 B, rounded up to whole wave-instructions)
 #define KM_PITCH 176            // LDS row pitch in bytes (44 dwords: 16 consecutive rows hit 16 distinct 4-bank groups)
-#define KM_EVCAP 2048           // events per wave and candidate cell
-#define KM_MAXPTS 4096          // candidate index must fit 12 bits
+#define KM_EVROWS 32            // event entries (tile, 16-bit row mask) per lane, group and candidate cell
+#define KM_MAXPTS 65535         // candidate index must fit 16 bits
+#define KM_LIST_WORDS (2 * KM_EVROWS * 64)       // one event list: [group][entry][lane] uint32
+#define KM_KAPPA 0.001220703125f                 // k = 1.25 * 2^-10
 
 struct KmGeom {
     Geom g;
-    int LP, qchunks;
+    int LP, qwaves;             // qwaves = 64-query groups per cell (of the largest cell)
     float tphi;
 };
+
+// list id of (query cell, 64-query wave, window slot)
+__device__ static inline size_t list_id(const KmGeom &a, int qcell, int qwave, int wslot)
+{
+    const int win = 2 * a.g.win + 1;
+    return ((size_t)qcell * a.qwaves + qwave) * (win * win) + wslot;
+}
 
 // ------------------------------------------------------------------------------------------------ prep
 // one thread per pixel of one image; which = 0: image 1 (queries), 1: image 2 (candidates)
 __global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restrict__ h, float *__restrict__ nrm,
-                                unsigned int *__restrict__ cellmax, int *__restrict__ flags, Geom g, int which)
+                                int *__restrict__ flags, Geom g, int which)
 {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= g.H * g.W) return;
     const float4 *s = reinterpret_cast<const float4 *>(d + (size_t)pix * DFLOW_DESC);
     _Float16 row[KM_K];
-    float ss = 0.0f;
+    float ss = 0.0f, sx = 0.0f;
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < DFLOW_DESC / 4; k++) {
@@ -61,66 +78,46 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restric
         float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float sc = KM_ALPHA * e[j];
-            bad |= !(fabsf(sc) < 60000.0f);          // also catches NaN
+            float sc = KM_ALPHA * e[j];                // exact (power of two)
+            bad |= !(sc >= 0.0f && sc < 60000.0f);     // negative, too large, NaN: the error bound would not hold
             _Float16 hv = (_Float16)sc;
             row[4 * k + j] = hv;
             float f = (float)hv;
-            ss = ss + f * f;
+            ss = ss + f * f;                           // |x~|^2
+            sx = sx + sc * sc;                         // |64 x|^2 from the unrounded values
         }
     }
-    if (which == 0) {
-        row[68] = (_Float16)-1.0f; row[69] = (_Float16)-1.0f; row[70] = (_Float16)-1.0f;
-    } else {
-        float hc = 0.5f * ss;
-        bad |= !(hc < 60000.0f);
-        _Float16 p1 = (_Float16)hc;
-        float r1 = hc - (float)p1;
-        _Float16 p2 = (_Float16)r1;
-        float r2 = r1 - (float)p2;
-        _Float16 p3 = (_Float16)r2;
-        row[68] = p1; row[69] = p2; row[70] = p3;
-    }
 #pragma unroll
-    for (int k = 71; k < KM_K; k++) row[k] = (_Float16)0.0f;
+    for (int k = DFLOW_DESC; k < KM_K; k++) row[k] = (_Float16)0.0f;
+    if (which == 0) {
+        row[68] = (_Float16)-1.0f; row[69] = (_Float16)-1.0f; row[70] = (_Float16)-1.0f;   // pass-1 selectors (h-)
+    } else {
+        const float h = 0.5f * sx;
+        bad |= !(h < 60000.0f);
+        // h- = h (1+2^-14)/(1-k) rounded up a little, h+ = h (1-2^-14)/(1+k) rounded down a little
+        const float hm = h * 1.0012840f, hp = h * 0.9987190f;
+        float r = hm;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { _Float16 pc = (_Float16)r; row[68 + i] = pc; r = r - (float)pc; }
+        r = hp;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { _Float16 pc = (_Float16)r; row[71 + i] = pc; r = r - (float)pc; }
+    }
     float4 *o = reinterpret_cast<float4 *>(h + (size_t)pix * KM_K);
     const float4 *r4 = reinterpret_cast<const float4 *>(row);
 #pragma unroll
     for (int k = 0; k < KM_K * 2 / 16; k++) o[k] = r4[k];
-    float n = sqrtf(ss) * 1.0001f;                   // a slight over-estimate of |x~| keeps eps on the safe side
-    nrm[pix] = n;
-    if (which == 1) atomicMax(&cellmax[g.celly(pix / g.W) * g.ncx + g.cellx(pix % g.W)], __float_as_uint(n));
+    if (which == 0) nrm[pix] = sqrtf(ss) * 1.0001f;   // a slight over-estimate of |q~|
     if (bad) atomicOr(flags, 1);
 }
 
-// ------------------------------------------------------------------------------------------------ main kernel
-struct KmPtrs {
-    const float *d1, *d2;          // float32 descriptors (exact distances, costs)
+// ------------------------------------------------------------------------------------------------ screen
+struct KmScreen {
     const _Float16 *h1, *h2;       // prepared f16 rows
     const float *qn;               // |q~| per image-1 pixel
-    const unsigned int *cellmax;   // max |c~| per image-2 cell (float bits)
-    uint32_t *proposals;
-    float *lcosts;
-    int *ovf_count;                // overflow list: entries (qcell, qchunk, ci, cj) for knn_fix_kernel
-    int4 *ovf_list;
-    int ovf_cap;
+    uint32_t *ev;                  // [list][2][KM_EVROWS][64]: (tile << 16) | row mask
+    uint8_t *ev_cnt;               // [list][2][64]; 255 = overflow
 };
-
-__device__ static inline float exact_dist(const float *__restrict__ q, const float *__restrict__ c)
-{
-    const float4 *q4 = reinterpret_cast<const float4 *>(q), *c4 = reinterpret_cast<const float4 *>(c);
-    float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < DFLOW_DESC / 4; k++) {
-        float4 u = q4[k], v = c4[k];
-        float e;
-        e = u.x - v.x; acc = __fmaf_rn(e, e, acc);
-        e = u.y - v.y; acc = __fmaf_rn(e, e, acc);
-        e = u.z - v.z; acc = __fmaf_rn(e, e, acc);
-        e = u.w - v.w; acc = __fmaf_rn(e, e, acc);
-    }
-    return acc;
-}
 
 __device__ static inline void top5_insert_desc(float (&a)[5], float m)
 {
@@ -136,22 +133,20 @@ __device__ static inline float max16(const f32x16 &v)
     return fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, v[15]));
 }
 
-__global__ void __launch_bounds__(KM_THREADS, 2) knn_mfma_kernel(KmGeom a, KmPtrs p)
+__global__ void __launch_bounds__(KM_THREADS, 3) knn_screen_kernel(KmGeom a, KmScreen p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *abuf = smem;                                                               // [2][KM_CHUNK][KM_PITCH]
-    uint32_t *evlist = reinterpret_cast<uint32_t *>(smem + 2 * KM_CHUNK * KM_PITCH);   // [KM_WAVES][KM_EVCAP]
-    unsigned long long *top = reinterpret_cast<unsigned long long *>(evlist + KM_WAVES * KM_EVCAP);   // [KM_QPB][5]
-    int *qpix_lds = reinterpret_cast<int *>(top + KM_QPB * 5);                          // [KM_QPB]
+    char *abuf = smem;                                                   // [2][KM_ABUF]
 
     const Geom g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     // ---- which (query cell, query chunk, candidate cell)
     const int win = 2 * g.win + 1;
+    const int qchunks = (a.qwaves + KM_WAVES - 1) / KM_WAVES;
     int b = blockIdx.x;
     const int wslot = b % (win * win); b /= win * win;
-    const int qchunk = b % a.qchunks; const int qcell = b / a.qchunks;
+    const int qchunk = b % qchunks; const int qcell = b / qchunks;
     const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
     const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
     if (qchunk * KM_QPB >= qnpts) return;
@@ -160,47 +155,55 @@ __global__ void __launch_bounds__(KM_THREADS, 2) knn_mfma_kernel(KmGeom a, KmPtr
     const int ncyw = cjmax - cjmin + 1;
     const int ci = cimin + wslot / ncyw, cj = cjmin + wslot % ncyw;      // reference order: ci outer, cj inner (Q2)
     if (ci > cimax) return;
-    const int slot_base = 5 * wslot;
     const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0, cnpts = ccw * (g.y1(cj) - cy0);
-    const float C = __uint_as_float(p.cellmax[cj * g.ncx + ci]);
+    const int qwave = qchunk * KM_WAVES + wave;
+    const bool wave_active = qwave * KM_QPW < qnpts;                   // idle waves only help staging (barriers stay block-uniform)
 
-    // ---- my queries: group gq (0/1), column col -> in-cell index, pixel; B fragments and eps
-    half8 bfrag[2][5];
-    float eps[2];
-    int qpix[2];
+    // ---- my queries: group gq (0/1), column col; B fragments (last k-step differs between the passes) and slack
+    half8 bfrag[2][5], blast2[2];
+    float sq[2];
 #pragma unroll
     for (int gq = 0; gq < 2; gq++) {
-        int qi = qchunk * KM_QPB + wave * KM_QPW + gq * 32 + col;
+        int qi = qwave * KM_QPW + gq * 32 + col;
         if (qi >= qnpts) qi = qnpts - 1;                                 // inactive columns shadow the last query
-        qpix[gq] = (qy0 + qi / qcw) * g.W + qx0 + qi % qcw;
-        const half8 *src = reinterpret_cast<const half8 *>(p.h1 + (size_t)qpix[gq] * KM_K);
+        const int qpix = (qy0 + qi / qcw) * g.W + qx0 + qi % qcw;
+        const half8 *src = reinterpret_cast<const half8 *>(p.h1 + (size_t)qpix * KM_K);
 #pragma unroll
         for (int s = 0; s < 5; s++) bfrag[gq][s] = src[2 * s + half];
-        if (half == 0) qpix_lds[wave * KM_QPW + gq * 32 + col] = qpix[gq];
-        float qn = p.qn[qpix[gq]];
-        eps[gq] = 1.25f * 0.0009765625f * (qn * C + 0.5f * C * C) + 1e-5f * (qn + C) + 1e-6f;
+        // k = 64..71 sit in half 0, k = 72..79 in half 1: pass 1 selects h- (k = 68..70), pass 2 h+ (k = 71..73)
+        half8 b2 = bfrag[gq][4];
+        if (half == 0) { b2[4] = (_Float16)0.0f; b2[5] = (_Float16)0.0f; b2[6] = (_Float16)0.0f; b2[7] = (_Float16)-1.0f; }
+        else { b2[0] = (_Float16)-1.0f; b2[1] = (_Float16)-1.0f; }
+        blast2[gq] = b2;
+        const float qn = p.qn[qpix];
+        sq[gq] = 1.52587890625e-5f * qn * qn + 1e-5f * qn + 1e-6f;       // 2^-16 |q~|^2 + absolute terms
     }
 
     const int nchunks = (cnpts + KM_CHUNK - 1) / KM_CHUNK;
-    // cooperative staging of one chunk: 96 rows x 10 pieces of 16 bytes
+    // Asynchronous staging of one chunk straight into LDS (global_load_lds_dwordx4: the LDS address is wave-uniform
+    // base + 16*lane, the global address is per lane).  The LDS image is 96 rows of 11 16-byte slots (10 data + 1
+    // pad = 176-byte pitch) = 1056 slots = 17 wave-instructions (the last one half used; the buffer is 17 KB).
+    // Pad slots and rows beyond the cell read a valid dummy address; such rows are masked after the MFMA.
     auto stage = [&](int chunk, int buf) {
-        for (int piece = tid; piece < KM_CHUNK * 10; piece += KM_THREADS) {
-            int r = piece / 10, part = piece % 10;
+        char *base = abuf + (size_t)buf * KM_ABUF;
+        for (int ins = wave; ins < 17; ins += KM_WAVES) {
+            const int slot = ins * 64 + lane;
+            int r = slot / 11, part = slot % 11;
             int idx = chunk * KM_CHUNK + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < cnpts) {
-                int cpix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
-                v = reinterpret_cast<const float4 *>(p.h2 + (size_t)cpix * KM_K)[part];
-            }
-            *reinterpret_cast<float4 *>(abuf + (size_t)buf * KM_CHUNK * KM_PITCH + r * KM_PITCH + part * 16) = v;
+            if (idx >= cnpts) idx = 0;
+            if (part > 9) part = 0;
+            const int cpix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
+            const char *src = reinterpret_cast<const char *>(p.h2 + (size_t)cpix * KM_K) + part * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(base + ins * 1024), 16, 0, 0);
         }
     };
 
     float a5[2][5];
     float thr[2] = {0.f, 0.f};
-    int evcount = 0;           // wave-uniform
-    bool overflow = false;     // wave-uniform
-    uint32_t *myev = evlist + wave * KM_EVCAP;
+    int cnt[2] = {0, 0};
+    const size_t lid = list_id(a, qcell, qwave, wslot);
+    uint32_t *myev = p.ev + lid * KM_LIST_WORDS + lane;
 
 #pragma unroll
     for (int gq = 0; gq < 2; gq++)
@@ -213,41 +216,38 @@ __global__ void __launch_bounds__(KM_THREADS, 2) knn_mfma_kernel(KmGeom a, KmPtr
         for (int chunk = 0; chunk < nchunks; chunk++) {
             const int buf = chunk & 1;
             if (chunk + 1 < nchunks) stage(chunk + 1, buf ^ 1);          // the other buffer was released by the barrier below
-            const char *ab = abuf + (size_t)buf * KM_CHUNK * KM_PITCH;
+            const char *ab = abuf + (size_t)buf * KM_ABUF;
+            if (wave_active) {
 #pragma unroll 1
-            for (int tile = 0; tile < KM_CHUNK / 32; tile++) {
-                const int cbase = chunk * KM_CHUNK + tile * 32;
-                if (cbase >= cnpts) break;
-                half8 af[5];
-                const char *arow = ab + (tile * 32 + col) * KM_PITCH + half * 16;
+                for (int tile = 0; tile < KM_CHUNK / 32; tile++) {
+                    const int cbase = chunk * KM_CHUNK + tile * 32;
+                    if (cbase >= cnpts) break;
+                    half8 af[5];
+                    const char *arow = ab + (tile * 32 + col) * KM_PITCH + half * 16;
 #pragma unroll
-                for (int s = 0; s < 5; s++) af[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
+                    for (int s = 0; s < 5; s++) af[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
 #pragma unroll
-                for (int gq = 0; gq < 2; gq++) {
-                    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int gq = 0; gq < 2; gq++) {
+                        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < 5; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[gq][s], acc, 0, 0, 0);
-                    if (pass == 0) {
-                        if (cbase + 32 > cnpts) {     // last, partial tile: rows beyond the cell must not enter the maxima
+                        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[gq][s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[4], pass == 0 ? bfrag[gq][4] : blast2[gq], acc, 0, 0, 0);
+                        if (cbase + 32 > cnpts) {     // last, partial tile: rows beyond the cell must never qualify
 #pragma unroll
                             for (int r = 0; r < 16; r++)
                                 if (cbase + (r & 3) + 8 * (r >> 2) + 4 * half >= cnpts) acc[r] = -INFINITY;
                         }
-                        top5_insert_desc(a5[gq], max16(acc));
-                    } else {
-                        const float th = thr[gq];
+                        if (pass == 0) {
+                            top5_insert_desc(a5[gq], max16(acc));
+                        } else {
+                            // 16-bit mask of the rows that qualify: bit r <-> accumulator register r
+                            const float th = thr[gq];
+                            uint32_t mask = 0;
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int idx = cbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const bool ev = acc[r] >= th && idx < cnpts;
-                            const unsigned long long m = __ballot(ev);
-                            if (m) {
-                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                const int slot = evcount + rank;
-                                if (ev) {
-                                    if (slot < KM_EVCAP) myev[slot] = ((uint32_t)(gq * 32 + col) << 12) | (uint32_t)idx;
-                                }
-                                evcount += __popcll(m);
+                            for (int r = 15; r >= 0; r--) mask = mask + mask + (acc[r] >= th ? 1u : 0u);
+                            if (mask) {
+                                myev[(size_t)(gq * KM_EVROWS + min(cnt[gq], KM_EVROWS - 1)) * 64] = ((uint32_t)(cbase >> 5) << 16) | mask;
+                                cnt[gq]++;
                             }
                         }
                     }
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(KM_THREADS, 2) knn_mfma_kernel(KmGeom a, KmPtr
             __syncthreads();
         }
         if (pass == 0) {
-            // merge the two half-lanes of every query, threshold = 5th largest tile-column maximum - 2 eps
+            // merge the two half-lanes of every query; pass-2 values v qualify iff (1+k) v >= (1-k) a5 - s_q
 #pragma unroll
             for (int gq = 0; gq < 2; gq++) {
                 float o[5];
@@ -264,55 +264,144 @@ __global__ void __launch_bounds__(KM_THREADS, 2) knn_mfma_kernel(KmGeom a, KmPtr
                 for (int i = 0; i < 5; i++) o[i] = __shfl_xor(a5[gq][i], 32);
 #pragma unroll
                 for (int i = 0; i < 5; i++) top5_insert_desc(a5[gq], o[i]);
-                thr[gq] = a5[gq][4] - 2.0f * eps[gq];
+                const float x = ((1.0f - KM_KAPPA) * a5[gq][4] - sq[gq]) / (1.0f + KM_KAPPA);
+                thr[gq] = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -3.0e38f);   // finite: masked rows (-inf) never pass '>='
             }
         }
     }
-    overflow = evcount > KM_EVCAP;
-
-    // ---- resolve: canonical float32 distance of every event, cascaded atomic minima into the owner's top-5
-    unsigned long long *mytop = top + (size_t)wave * KM_QPW * 5;
-    for (int i = lane; i < KM_QPW * 5; i += 64) mytop[i] = ~0ull;
-    __builtin_amdgcn_wave_barrier();
-    const int nev = overflow ? 0 : evcount;
-    for (int e = lane; e < nev; e += 64) {
-        const uint32_t key = myev[e];
-        const int owner = key >> 12, idx = key & 0xFFF;
-        const int opix = qpix_lds[wave * KM_QPW + owner];
-        const int cpix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
-        const float dist = exact_dist(p.d1 + (size_t)opix * DFLOW_DESC, p.d2 + (size_t)cpix * DFLOW_DESC);
-        unsigned long long k64 = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx;
-        unsigned long long *t5 = mytop + owner * 5;
+    if (!wave_active) return;
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            unsigned long long old = atomicMin(&t5[j], k64);
-            k64 = old > k64 ? old : k64;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
+    for (int gq = 0; gq < 2; gq++) p.ev_cnt[lid * 128 + gq * 64 + lane] = (uint8_t)(cnt[gq] > KM_EVROWS ? 255 : cnt[gq]);
+}
 
-    if (overflow) {
+// ------------------------------------------------------------------------------------------------ resolve
+struct KmResolve {
+    const float *d1, *d2;
+    const uint32_t *ev;
+    const uint8_t *ev_cnt;
+    uint32_t *proposals;
+    float *lcosts;
+    int *ovf_count;                // overflow list: entries (qcell, first query, ci, cj) for knn_fix_kernel
+    int4 *ovf_list;
+    int ovf_cap;
+};
+
+// sorted insertion of (key, cost) into an ascending top-5; key order = canonical (distance, index) order
+__device__ static inline void key_insert(unsigned long long (&k)[5], float (&c)[5], unsigned long long x, float xc)
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const bool lt = x < k[i];
+        const unsigned long long lo = lt ? x : k[i], hi = lt ? k[i] : x;
+        const float clo = lt ? xc : c[i], chi = lt ? c[i] : xc;
+        k[i] = lo; c[i] = clo; x = hi; xc = chi;
+    }
+}
+
+// one wave per event list; lane = (query column lane&31, candidate half lane>>5), both groups in turn
+__global__ void __launch_bounds__(256, 3) knn_resolve_kernel(KmGeom a, KmResolve p, int nlists)
+{
+    const Geom g = a.g;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int lid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lid >= nlists) return;
+    const int win = 2 * g.win + 1;
+    int b = lid;
+    const int wslot = b % (win * win); b /= win * win;
+    const int qwave = b % a.qwaves; const int qcell = b / a.qwaves;
+    const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
+    const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
+    if (qwave * KM_QPW >= qnpts) return;
+    const int cimin = max(0, qci - g.win), cimax = min(g.ncx - 1, qci + g.win);
+    const int cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
+    const int ncyw = cjmax - cjmin + 1;
+    const int ci = cimin + wslot / ncyw, cj = cjmin + wslot % ncyw;
+    if (ci > cimax) return;
+    const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0;
+
+    const int c0 = p.ev_cnt[(size_t)lid * 128 + lane], c1 = p.ev_cnt[(size_t)lid * 128 + 64 + lane];
+    if (__ballot(c0 == 255 || c1 == 255)) {          // some lane ran out of list space: exact redo by knn_fix_kernel
         if (lane == 0) {
             int pos = atomicAdd(p.ovf_count, 1);
-            if (pos < p.ovf_cap) p.ovf_list[pos] = make_int4(qcell, qchunk * KM_QPB + wave * KM_QPW, ci, cj);
+            if (pos < p.ovf_cap) p.ovf_list[pos] = make_int4(qcell, qwave * KM_QPW, ci, cj);
         }
         return;
     }
-    // ---- emit (daisy i flann.py:174-180): lane = query (group lane>>5, column lane&31)
-    {
-        const int qi = qchunk * KM_QPB + wave * KM_QPW + lane;
-        const int mypix = qpix_lds[wave * KM_QPW + lane];
-        if (qi < qnpts) {
-            const int qy = mypix / g.W, qx = mypix % g.W;
-            const unsigned long long *t5 = mytop + lane * 5;
-            for (int j = 0; j < 5; j++) {
-                const int idx = (int)(t5[j] & 0xFFFFFFFFu);
-                const int ty = cy0 + idx / ccw, tx = cx0 + idx % ccw;
-                const float s = l1_cost_np(p.d1 + (size_t)mypix * DFLOW_DESC, p.d2 + ((size_t)ty * g.W + tx) * DFLOW_DESC);
-                p.proposals[(size_t)mypix * a.LP + slot_base + j] = pack_flow(ty - qy, tx - qx);
-                p.lcosts[(size_t)mypix * a.LP + slot_base + j] = s < a.tphi ? s : a.tphi;
+    unsigned long long keys[2][5];
+    float costs[2][5];
+#pragma unroll
+    for (int gq = 0; gq < 2; gq++) {
+        int qi = qwave * KM_QPW + gq * 32 + (lane & 31);
+        if (qi >= qnpts) qi = qnpts - 1;
+        const size_t qpix = (size_t)(qy0 + qi / qcw) * g.W + qx0 + qi % qcw;
+        float q[DFLOW_DESC];
+        {
+            const float4 *s = reinterpret_cast<const float4 *>(p.d1 + qpix * DFLOW_DESC);
+#pragma unroll
+            for (int k = 0; k < DFLOW_DESC / 4; k++) { float4 v = s[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) { keys[gq][i] = ~0ull; costs[gq][i] = 0.0f; }
+        const int n = gq == 0 ? c0 : c1;
+        const uint32_t *ev = p.ev + (size_t)lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + lane;
+        for (int e = 0; e < n; e++) {
+            const uint32_t entry = ev[e * 64];
+            const int tbase = (int)(entry >> 16) * 32 + 4 * half;
+            uint32_t mask = entry & 0xFFFFu;
+            while (mask) {
+                const int r = __ffs(mask) - 1;
+                mask &= mask - 1;
+                const int idx = tbase + (r & 3) + 8 * (r >> 2);
+                const float4 *c4 = reinterpret_cast<const float4 *>(p.d2 + ((size_t)(cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * DFLOW_DESC);
+                // Canonical distance: sequential fmaf chain.  Its partial sums never decrease, so the chain stops as
+                // soon as it exceeds the lane's current 5th best: such a candidate cannot enter the top 5.
+                // The L1 cost (numpy pairwise order: 8 running sums, tree, 4 leftovers) rides along.
+                const float worst = __uint_as_float((unsigned)(keys[gq][4] >> 32));
+                float acc = 0.0f, rs[8], tail[4];
+                bool dead = false;
+#pragma unroll
+                for (int k0 = 0; k0 < DFLOW_DESC / 4; k0 += 4) {
+                    if (!dead) {
+#pragma unroll
+                        for (int k = k0; k < k0 + 4 && k < DFLOW_DESC / 4; k++) {
+                            const float4 v = c4[k];
+                            const float e0 = q[4 * k] - v.x, e1 = q[4 * k + 1] - v.y, e2 = q[4 * k + 2] - v.z, e3 = q[4 * k + 3] - v.w;
+                            acc = __fmaf_rn(e0, e0, acc); acc = __fmaf_rn(e1, e1, acc);
+                            acc = __fmaf_rn(e2, e2, acc); acc = __fmaf_rn(e3, e3, acc);
+                            const int j = (4 * k) & 7;
+                            if (k < 2) { rs[j] = fabsf(e0); rs[j + 1] = fabsf(e1); rs[j + 2] = fabsf(e2); rs[j + 3] = fabsf(e3); }
+                            else if (k < 16) { rs[j] = rs[j] + fabsf(e0); rs[j + 1] = rs[j + 1] + fabsf(e1); rs[j + 2] = rs[j + 2] + fabsf(e2); rs[j + 3] = rs[j + 3] + fabsf(e3); }
+                            else { tail[0] = fabsf(e0); tail[1] = fabsf(e1); tail[2] = fabsf(e2); tail[3] = fabsf(e3); }
+                        }
+                        dead = acc > worst;
+                    }
+                }
+                if (dead) continue;
+                float l1 = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+                l1 = l1 + tail[0]; l1 = l1 + tail[1]; l1 = l1 + tail[2]; l1 = l1 + tail[3];
+                key_insert(keys[gq], costs[gq], ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)idx, l1);
             }
+        }
+        // the other half-lane screened the other 16 rows of every tile: merge
+        unsigned long long ok[5]; float oc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { ok[i] = __shfl_xor(keys[gq][i], 32); oc[i] = __shfl_xor(costs[gq][i], 32); }
+#pragma unroll
+        for (int i = 0; i < 5; i++) key_insert(keys[gq], costs[gq], ok[i], oc[i]);
+    }
+    // ---- emit (daisy i flann.py:174-180): lane l < 32 writes group 0 / column l, lane l >= 32 group 1 / column l-32
+    const int qi = qwave * KM_QPW + lane;
+    if (qi < qnpts) {
+        const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
+        const size_t pix = (size_t)qy * g.W + qx;
+        const int slot_base = 5 * wslot;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int idx = (int)((half == 0 ? keys[0][j] : keys[1][j]) & 0xFFFFFFFFu);
+            const float s = half == 0 ? costs[0][j] : costs[1][j];
+            const int ty = cy0 + idx / ccw, tx = cx0 + idx % ccw;
+            p.proposals[pix * a.LP + slot_base + j] = pack_flow(ty - qy, tx - qx);
+            p.lcosts[pix * a.LP + slot_base + j] = s < a.tphi ? s : a.tphi;
         }
     }
 }
@@ -338,18 +427,32 @@ __global__ void knn_finalize_kernel(Geom g, int LP, uint32_t *__restrict__ propo
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+static int max_cell_points(const Geom &g)
+{
+    return (g.x1(g.ncx - 1) - g.x0(g.ncx - 1)) * (g.y1(g.ncy - 1) - g.y0(g.ncy - 1));
+}
+
+static size_t num_lists(const dflow_params *p)
+{
+    Geom g = make_geom(p);
+    size_t qwaves = (max_cell_points(g) + KM_QPW - 1) / KM_QPW, win = 2 * g.win + 1;
+    return (size_t)g.ncx * g.ncy * qwaves * win * win;
+}
+
+#define KM_OVF_CAP 8192
+
 size_t knn_mfma_ws_bytes(const dflow_params *p)
 {
     size_t N = (size_t)p->pich * p->picw;
-    size_t ncells = (size_t)(p->picw / p->cellw) * (p->pich / p->cellh);
-    return 2 * N * KM_K * sizeof(_Float16) + 2 * N * sizeof(float) + ncells * sizeof(unsigned) + 256 + 4096 * sizeof(int4) + 256;
+    size_t nl = num_lists(p);
+    return 2 * N * KM_K * sizeof(_Float16) + N * sizeof(float) + 512 +
+           KM_OVF_CAP * sizeof(int4) + nl * (KM_LIST_WORDS * sizeof(uint32_t) + 128) + 1024;
 }
 
 bool knn_mfma_supported(const dflow_params *p)
 {
     Geom g = make_geom(p);
-    int maxpts = (g.x1(g.ncx - 1) - g.x0(g.ncx - 1)) * (g.y1(g.ncy - 1) - g.y0(g.ncy - 1));
-    return maxpts <= KM_MAXPTS && p->window >= 0 && p->window <= 2;
+    return max_cell_points(g) <= KM_MAXPTS && p->window >= 0 && p->window <= 2;
 }
 
 int launch_knn_fix(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
@@ -359,44 +462,42 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
                     int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s)
 {
     Geom g = make_geom(p);
-    size_t N = (size_t)g.H * g.W, ncells = (size_t)g.ncx * g.ncy;
+    size_t N = (size_t)g.H * g.W, nl = num_lists(p);
+    auto align256 = [](char *w) { return (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255); };
     char *w = (char *)ws;
     _Float16 *h1 = (_Float16 *)w; w += N * KM_K * sizeof(_Float16);
     _Float16 *h2 = (_Float16 *)w; w += N * KM_K * sizeof(_Float16);
     float *qn = (float *)w; w += N * sizeof(float);
-    float *cn = (float *)w; w += N * sizeof(float);
-    unsigned *cellmax = (unsigned *)w; w += ncells * sizeof(unsigned);
-    w = (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+    w = align256(w);
     int *ctr = (int *)w; w += 256;              // ctr[0] = overflow count, ctr[1] = flags
-    int4 *ovf = (int4 *)w;
-    const int ovf_cap = 4096;
-    if (hipMemsetAsync(cellmax, 0, ncells * sizeof(unsigned), s) != hipSuccess || hipMemsetAsync(ctr, 0, 256, s) != hipSuccess)
+    int4 *ovf = (int4 *)w; w += KM_OVF_CAP * sizeof(int4);
+    w = align256(w);
+    uint32_t *ev = (uint32_t *)w; w += nl * KM_LIST_WORDS * sizeof(uint32_t);
+    uint8_t *ev_cnt = (uint8_t *)w;
+    if (hipMemsetAsync(ctr, 0, 256, s) != hipSuccess)
         return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_knn_mfma");
     int nb = (int)((N + 255) / 256);
-    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, h1, qn, cellmax, ctr + 1, g, 0);
-    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d2, h2, cn, cellmax, ctr + 1, g, 1);
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, h1, qn, ctr + 1, g, 0);
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d2, h2, (float *)nullptr, ctr + 1, g, 1);
 
     KmGeom a;
     a.g = g; a.LP = p->label_pitch; a.tphi = p->tphi;
-    int maxpts = (g.x1(g.ncx - 1) - g.x0(g.ncx - 1)) * (g.y1(g.ncy - 1) - g.y0(g.ncy - 1));
-    a.qchunks = (maxpts + KM_QPB - 1) / KM_QPB;
-    KmPtrs q;
-    q.d1 = d1; q.d2 = d2; q.h1 = h1; q.h2 = h2; q.qn = qn; q.cellmax = cellmax; q.proposals = proposals; q.lcosts = lcosts;
-    q.ovf_count = ctr; q.ovf_list = ovf; q.ovf_cap = ovf_cap;
+    a.qwaves = (max_cell_points(g) + KM_QPW - 1) / KM_QPW;
     int win = 2 * g.win + 1;
-    int nblocks = g.ncx * g.ncy * a.qchunks * win * win;
-    size_t shmem = 2 * KM_CHUNK * KM_PITCH + KM_WAVES * KM_EVCAP * sizeof(uint32_t) + KM_QPB * 5 * sizeof(unsigned long long) +
-                   KM_QPB * sizeof(int);
-    static thread_local bool attr_set = false;   // > 64 KB of dynamic LDS needs an explicit opt-in (per device context)
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)knn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
-            return dflow_set_error(DFLOW_EHIP, "hipFuncSetAttribute(knn_mfma_kernel, %zu bytes of LDS) failed", shmem);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(knn_mfma_kernel, dim3(nblocks), dim3(KM_THREADS), shmem, s, a, q);
-    int rc = dflow_check_launch("knn_mfma_kernel");
+    int qchunks = (a.qwaves + KM_WAVES - 1) / KM_WAVES;
+    KmScreen sc;
+    sc.h1 = h1; sc.h2 = h2; sc.qn = qn; sc.ev = ev; sc.ev_cnt = ev_cnt;
+    size_t shmem = 2 * KM_ABUF;
+    hipLaunchKernelGGL(knn_screen_kernel, dim3(g.ncx * g.ncy * qchunks * win * win), dim3(KM_THREADS), shmem, s, a, sc);
+    int rc = dflow_check_launch("knn_screen_kernel");
     if (rc) return rc;
-    rc = launch_knn_fix(p, d1, d2, proposals, lcosts, ctr, ovf, ovf_cap, ctr + 1, s);
+    KmResolve rs;
+    rs.d1 = d1; rs.d2 = d2; rs.ev = ev; rs.ev_cnt = ev_cnt; rs.proposals = proposals; rs.lcosts = lcosts;
+    rs.ovf_count = ctr; rs.ovf_list = ovf; rs.ovf_cap = KM_OVF_CAP;
+    hipLaunchKernelGGL(knn_resolve_kernel, dim3((unsigned)((nl + 3) / 4)), dim3(256), 0, s, a, rs, (int)nl);
+    rc = dflow_check_launch("knn_resolve_kernel");
+    if (rc) return rc;
+    rc = launch_knn_fix(p, d1, d2, proposals, lcosts, ctr, ovf, KM_OVF_CAP, ctr + 1, s);
     if (rc) return rc;
     hipLaunchKernelGGL(knn_finalize_kernel, dim3(nb), dim3(256), 0, s, g, a.LP, proposals, lcosts, nprop, bestlabels);
     return dflow_check_launch("knn_finalize_kernel");

@@ -1,5 +1,5 @@
 import sys, importlib, time, numpy as np, torch
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 synth = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.synth")
 pl = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.pipeline")
 H,W = 436,1024
