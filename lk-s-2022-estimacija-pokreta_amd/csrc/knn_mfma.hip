@@ -36,8 +36,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define KM_ALPHA 64.0f
 #define KM_K 80                 // f16 per prepared row (160 bytes)
-#define KM_THREADS 256
-#define KM_WAVES 4
+#define KM_WAVES 8
+#define KM_THREADS (64 * KM_WAVES)
 #define KM_QPW 64               // queries per wave: 2 column groups of 32
 #define KM_QPB (KM_WAVES * KM_QPW)
 #define KM_CHUNK 96             // candidates per LDS chunk (3 tiles of 32)
@@ -79,7 +79,9 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restric
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float sc = KM_ALPHA * e[j];                // exact (power of two)
-            bad |= !(sc >= 0.0f && sc < 60000.0f);     // negative, too large, NaN: the error bound would not hold
+            // negative, too large or NaN (tested on the bits: this file is compiled with -fno-honor-nans):
+            // the error bound would not hold
+            bad |= sc < 0.0f || sc >= 60000.0f || (__float_as_uint(sc) & 0x7FFFFFFFu) > 0x7F800000u;
             _Float16 hv = (_Float16)sc;
             row[4 * k + j] = hv;
             float f = (float)hv;
@@ -93,7 +95,7 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restric
         row[68] = (_Float16)-1.0f; row[69] = (_Float16)-1.0f; row[70] = (_Float16)-1.0f;   // pass-1 selectors (h-)
     } else {
         const float h = 0.5f * sx;
-        bad |= !(h < 60000.0f);
+        bad |= h >= 50000.0f || (__float_as_uint(h) & 0x7FFFFFFFu) > 0x7F800000u;
         // h- = h (1+2^-14)/(1-k) rounded up a little, h+ = h (1-2^-14)/(1+k) rounded down a little
         const float hm = h * 1.0012840f, hp = h * 0.9987190f;
         float r = hm;
@@ -108,6 +110,12 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restric
 #pragma unroll
     for (int k = 0; k < KM_K * 2 / 16; k++) o[k] = r4[k];
     if (which == 0) nrm[pix] = sqrtf(ss) * 1.0001f;   // a slight over-estimate of |q~|
+    if (which == 1 && pix == 0) {
+        // sentinel row behind the image (row index H*W): h- = h+ = 60000, everything else 0.  Tile rows beyond the end
+        // of a cell are staged from it: their MFMA value is -60000, below every real one (real h < 50000).
+        _Float16 *sr = h + (size_t)g.H * g.W * KM_K;
+        for (int k = 0; k < KM_K; k++) sr[k] = (_Float16)((k == 68 || k == 71) ? 60000.0f : 0.0f);
+    }
     if (bad) atomicOr(flags, 1);
 }
 
@@ -133,7 +141,7 @@ __device__ static inline float max16(const f32x16 &v)
     return fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, v[15]));
 }
 
-__global__ void __launch_bounds__(KM_THREADS, 3) knn_screen_kernel(KmGeom a, KmScreen p)
+__global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmScreen p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *abuf = smem;                                                   // [2][KM_ABUF]
@@ -141,20 +149,21 @@ __global__ void __launch_bounds__(KM_THREADS, 3) knn_screen_kernel(KmGeom a, KmS
     const Geom g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
-    // ---- which (query cell, query chunk, candidate cell)
+    // ---- which (candidate cell, query cell in its window, query chunk).  Candidate-cell-major order: the blocks in
+    // flight at any time stream the same few candidate cells, so their rows stay in the XCDs' L2.
     const int win = 2 * g.win + 1;
     const int qchunks = (a.qwaves + KM_WAVES - 1) / KM_WAVES;
     int b = blockIdx.x;
-    const int wslot = b % (win * win); b /= win * win;
-    const int qchunk = b % qchunks; const int qcell = b / qchunks;
-    const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
+    const int qchunk = b % qchunks; b /= qchunks;
+    const int qslot = b % (win * win); const int ccell = b / (win * win);
+    const int ci = ccell % g.ncx, cj = ccell / g.ncx;
+    const int qci = ci - g.win + qslot / win, qcj = cj - g.win + qslot % win;
+    if (qci < 0 || qci >= g.ncx || qcj < 0 || qcj >= g.ncy) return;
+    const int qcell = qcj * g.ncx + qci;
     const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
     if (qchunk * KM_QPB >= qnpts) return;
-    const int cimin = max(0, qci - g.win), cimax = min(g.ncx - 1, qci + g.win);
-    const int cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
-    const int ncyw = cjmax - cjmin + 1;
-    const int ci = cimin + wslot / ncyw, cj = cjmin + wslot % ncyw;      // reference order: ci outer, cj inner (Q2)
-    if (ci > cimax) return;
+    const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
+    const int wslot = (ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin);   // reference order: ci outer, cj inner (Q2)
     const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0, cnpts = ccw * (g.y1(cj) - cy0);
     const int qwave = qchunk * KM_WAVES + wave;
     const bool wave_active = qwave * KM_QPW < qnpts;                   // idle waves only help staging (barriers stay block-uniform)
@@ -183,16 +192,15 @@ __global__ void __launch_bounds__(KM_THREADS, 3) knn_screen_kernel(KmGeom a, KmS
     // Asynchronous staging of one chunk straight into LDS (global_load_lds_dwordx4: the LDS address is wave-uniform
     // base + 16*lane, the global address is per lane).  The LDS image is 96 rows of 11 16-byte slots (10 data + 1
     // pad = 176-byte pitch) = 1056 slots = 17 wave-instructions (the last one half used; the buffer is 17 KB).
-    // Pad slots and rows beyond the cell read a valid dummy address; such rows are masked after the MFMA.
+    // Pad slots re-read part 0; rows beyond the cell read the sentinel row (MFMA value -60000 < every real one).
     auto stage = [&](int chunk, int buf) {
         char *base = abuf + (size_t)buf * KM_ABUF;
         for (int ins = wave; ins < 17; ins += KM_WAVES) {
             const int slot = ins * 64 + lane;
             int r = slot / 11, part = slot % 11;
-            int idx = chunk * KM_CHUNK + r;
-            if (idx >= cnpts) idx = 0;
+            const int idx = chunk * KM_CHUNK + r;
             if (part > 9) part = 0;
-            const int cpix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
+            const int cpix = idx < cnpts ? (cy0 + idx / ccw) * g.W + cx0 + idx % ccw : g.H * g.W;   // else: sentinel row
             const char *src = reinterpret_cast<const char *>(p.h2 + (size_t)cpix * KM_K) + part * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(base + ins * 1024), 16, 0, 0);
@@ -231,20 +239,19 @@ __global__ void __launch_bounds__(KM_THREADS, 3) knn_screen_kernel(KmGeom a, KmS
                         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[gq][s], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[4], pass == 0 ? bfrag[gq][4] : blast2[gq], acc, 0, 0, 0);
-                        if (cbase + 32 > cnpts) {     // last, partial tile: rows beyond the cell must never qualify
-#pragma unroll
-                            for (int r = 0; r < 16; r++)
-                                if (cbase + (r & 3) + 8 * (r >> 2) + 4 * half >= cnpts) acc[r] = -INFINITY;
-                        }
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[4], bfrag[gq][4], acc, 0, 0, 0);
                         if (pass == 0) {
                             top5_insert_desc(a5[gq], max16(acc));
                         } else {
                             // 16-bit mask of the rows that qualify: bit r <-> accumulator register r
                             const float th = thr[gq];
-                            uint32_t mask = 0;
+                            // The compiler pads MFMA -> VALU hazards only for instructions it emits itself, so a plain
+                            // max over the accumulator comes first and the asm below is made to depend on it.
+                            uint32_t mask = max16(acc) >= th ? 0u : 0x10000u;   // bit 16 set <=> no row qualifies
 #pragma unroll
-                            for (int r = 15; r >= 0; r--) mask = mask + mask + (acc[r] >= th ? 1u : 0u);
+                            for (int r = 15; r >= 0; r--)   // mask = 2 mask + (acc[r] >= th): compare into vcc, add with carry-in
+                                asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(acc[r]), "v"(th) : "vcc");
+                            mask &= 0xFFFFu;
                             if (mask) {
                                 myev[(size_t)(gq * KM_EVROWS + min(cnt[gq], KM_EVROWS - 1)) * 64] = ((uint32_t)(cbase >> 5) << 16) | mask;
                                 cnt[gq]++;
@@ -265,7 +272,8 @@ __global__ void __launch_bounds__(KM_THREADS, 3) knn_screen_kernel(KmGeom a, KmS
 #pragma unroll
                 for (int i = 0; i < 5; i++) top5_insert_desc(a5[gq], o[i]);
                 const float x = ((1.0f - KM_KAPPA) * a5[gq][4] - sq[gq]) / (1.0f + KM_KAPPA);
-                thr[gq] = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -3.0e38f);   // finite: masked rows (-inf) never pass '>='
+                thr[gq] = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -55000.0f);   // real values are > -50000, sentinel rows -60000
+                bfrag[gq][4] = blast2[gq];                                      // pass 2 selects h+
             }
         }
     }
@@ -341,7 +349,7 @@ __global__ void __launch_bounds__(256, 3) knn_resolve_kernel(KmGeom a, KmResolve
             for (int k = 0; k < DFLOW_DESC / 4; k++) { float4 v = s[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
         }
 #pragma unroll
-        for (int i = 0; i < 5; i++) { keys[gq][i] = ~0ull; costs[gq][i] = 0.0f; }
+        for (int i = 0; i < 5; i++) { keys[gq][i] = 0x7F800000FFFFFFFFull; costs[gq][i] = 0.0f; }   // (+inf, no index)
         const int n = gq == 0 ? c0 : c1;
         const uint32_t *ev = p.ev + (size_t)lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + lane;
         for (int e = 0; e < n; e++) {
@@ -359,11 +367,13 @@ __global__ void __launch_bounds__(256, 3) knn_resolve_kernel(KmGeom a, KmResolve
                 const float worst = __uint_as_float((unsigned)(keys[gq][4] >> 32));
                 float acc = 0.0f, rs[8], tail[4];
                 bool dead = false;
+                // three waits per event at most: 4 + 6 + 7 float4
 #pragma unroll
-                for (int k0 = 0; k0 < DFLOW_DESC / 4; k0 += 4) {
+                for (int seg = 0; seg < 3; seg++) {
+                    const int ka = seg == 0 ? 0 : (seg == 1 ? 4 : 10), kb = seg == 0 ? 4 : (seg == 1 ? 10 : 17);
                     if (!dead) {
 #pragma unroll
-                        for (int k = k0; k < k0 + 4 && k < DFLOW_DESC / 4; k++) {
+                        for (int k = ka; k < kb; k++) {
                             const float4 v = c4[k];
                             const float e0 = q[4 * k] - v.x, e1 = q[4 * k + 1] - v.y, e2 = q[4 * k + 2] - v.z, e3 = q[4 * k + 3] - v.w;
                             acc = __fmaf_rn(e0, e0, acc); acc = __fmaf_rn(e1, e1, acc);
@@ -445,7 +455,7 @@ size_t knn_mfma_ws_bytes(const dflow_params *p)
 {
     size_t N = (size_t)p->pich * p->picw;
     size_t nl = num_lists(p);
-    return 2 * N * KM_K * sizeof(_Float16) + N * sizeof(float) + 512 +
+    return (2 * N + 1) * KM_K * sizeof(_Float16) + N * sizeof(float) + 512 +
            KM_OVF_CAP * sizeof(int4) + nl * (KM_LIST_WORDS * sizeof(uint32_t) + 128) + 1024;
 }
 
@@ -466,7 +476,7 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     auto align256 = [](char *w) { return (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255); };
     char *w = (char *)ws;
     _Float16 *h1 = (_Float16 *)w; w += N * KM_K * sizeof(_Float16);
-    _Float16 *h2 = (_Float16 *)w; w += N * KM_K * sizeof(_Float16);
+    _Float16 *h2 = (_Float16 *)w; w += (N + 1) * KM_K * sizeof(_Float16);   // + sentinel row
     float *qn = (float *)w; w += N * sizeof(float);
     w = align256(w);
     int *ctr = (int *)w; w += 256;              // ctr[0] = overflow count, ctr[1] = flags

@@ -1,0 +1,32 @@
+import sys, os, importlib, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+synth = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.synth")
+pl = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.pipeline")
+H,W = 436,1024
+img1,img2,gt = synth.make_pair(H,W,seed=2022)
+df = pl.DiscreteFlow(H,W,seed=99)
+df.load_pair(img1,img2); df.generisi(); torch.cuda.synchronize()
+N=H*W
+def al(x): return (x+255)//256*256
+off = (2*N+1)*160 + N*4
+base = df.ws.data_ptr()
+off = al(base+off)-base
+ctr = df.ws[off:off+8].cpu().numpy().view(np.int32); print('ovf count, flags', ctr)
+off += 256 + 8192*16
+off = al(base+off)-base
+ncx,ncy=16,16; qwaves=(64*31+63)//64; nl = ncx*ncy*qwaves*25
+ev = df.ws[off:off+nl*4096*4]
+cnt = df.ws[off+nl*4096*4: off+nl*4096*4+nl*128].cpu().numpy().reshape(nl,2,64)
+# active lists: those with qwave*64 < qnpts and valid slot: approximate by cnt>0 any
+act = cnt.reshape(nl,-1).max(1)>0
+c = cnt[act].astype(np.int32)
+print('lists', nl, 'active', act.sum(), 'entries/lane mean %.2f p99 %d max %d'%(c.mean(), np.percentile(c,99), c.max()))
+evw = ev.cpu().numpy().view(np.uint32).reshape(nl,2,32,64)[act]
+# count events = popcount of masks for valid entries
+masks = evw & 0xFFFF
+valid = np.arange(32)[None,None,:,None] < c[:,:,None,:]
+pc = np.zeros(masks.shape, np.int32)
+m = masks.copy()
+for i in range(16): pc += (m>>i)&1
+evs = (pc*valid).sum(2)   # per list, group, lane
+print('events/lane mean %.2f p99 %d max %d ; events per query (2 lanes) mean %.2f'%(evs.mean(), np.percentile(evs,99), evs.max(), (evs[:,:,:32]+evs[:,:,32:]).mean()))
