@@ -42,6 +42,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KM_QPB (KM_WAVES * KM_QPW)
 #define KM_CHUNK 96             // candidates per LDS chunk (3 tiles of 32)
 #define KM_ABUF (17 * 1024)      // bytes per staged chunk buffer (96 rows x 176 B, rounded up to whole wave-instructions)
+#define KM_NBUF 4                // ring of staged chunks: the DMA runs 3 chunks ahead of the MFMAs
 #define KM_PITCH 176            // LDS row pitch in bytes (44 dwords: 16 consecutive rows hit 16 distinct 4-bank groups)
 #define KM_EVROWS 32            // event entries (tile, 16-bit row mask) per lane, group and candidate cell
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
@@ -144,7 +145,7 @@ __device__ static inline float max16(const f32x16 &v)
 __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmScreen p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *abuf = smem;                                                   // [2][KM_ABUF]
+    char *abuf = smem;                                                   // [KM_NBUF][KM_ABUF]
 
     const Geom g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,12 +219,23 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 #pragma unroll
         for (int i = 0; i < 5; i++) a5[gq][i] = -INFINITY;
 
+    // A wave issues 3 (wave 0) or 2 DMA instructions per chunk.  Before the barrier that publishes chunk c+1 it waits
+    // until only the DMAs of chunks c+2 and c+3 (2 x its per-chunk count) may still be in flight; event stores issued
+    // in between only make that wait more conservative.  Chunks past the end are still "staged" (sentinel rows) so
+    // that the counts stay uniform.
+    auto wait_ring = [&]() {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
     for (int pass = 0; pass < 2; pass++) {
-        stage(0, 0);
-        __syncthreads();
+        stage(0, 0); stage(1, 1); stage(2, 2);
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         for (int chunk = 0; chunk < nchunks; chunk++) {
-            const int buf = chunk & 1;
-            if (chunk + 1 < nchunks) stage(chunk + 1, buf ^ 1);          // the other buffer was released by the barrier below
+            const int buf = chunk & (KM_NBUF - 1);
+            stage(chunk + 3, (chunk + 3) & (KM_NBUF - 1));                // that buffer was released by the previous barrier
             const char *ab = abuf + (size_t)buf * KM_ABUF;
             if (wave_active) {
 #pragma unroll 1
@@ -260,8 +272,10 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
                     }
                 }
             }
-            __syncthreads();
+            wait_ring();
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the over-staged chunks before the buffers are reused
+        __builtin_amdgcn_s_barrier();
         if (pass == 0) {
             // merge the two half-lanes of every query; pass-2 values v qualify iff (1+k) v >= (1-k) a5 - s_q
 #pragma unroll
@@ -497,7 +511,7 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     int qchunks = (a.qwaves + KM_WAVES - 1) / KM_WAVES;
     KmScreen sc;
     sc.h1 = h1; sc.h2 = h2; sc.qn = qn; sc.ev = ev; sc.ev_cnt = ev_cnt;
-    size_t shmem = 2 * KM_ABUF;
+    size_t shmem = (size_t)KM_NBUF * KM_ABUF;
     hipLaunchKernelGGL(knn_screen_kernel, dim3(g.ncx * g.ncy * qchunks * win * win), dim3(KM_THREADS), shmem, s, a, sc);
     int rc = dflow_check_launch("knn_screen_kernel");
     if (rc) return rc;
