@@ -13,7 +13,7 @@
  *   - Return 0 on success, a negative DFLOW_E* code otherwise; dflow_last_error() gives the message
  *     (thread-local).  No global state; re-entrant across devices.
  *
- * Device layouts (H = pich, W = picw, LP = label_pitch >= maxnprop, multiple of 4)
+ * Device layouts (H = pich, W = picw, LP = label_pitch >= maxnprop, multiple of 16)
  *   image      uint8   (H,W,3)   BGR, as cv2.imread returns it            daisy i flann.py:26-27,52-53
  *   descr      float32 (H,W,68)  row y*W+x = keypoint order               daisy i flann.py:69-77
  *   proposals  uint32  (H,W,LP)  one label = int16 dy | int16 dx << 16,   daisy i flann.py:89 (int64 (H,W,150,2), -1 fill)
@@ -57,7 +57,7 @@ typedef struct dflow_params {
     float sigma;                 /* daisy i flann.py:208  (8)  */
     double lamda;                /* daisy i flann.py:48   (0.05) */
     uint64_t seed;               /* key of the counter-based sampler (reference: unseeded np.random, :219) */
-    int32_t label_pitch;         /* LP, elements per pixel in proposals/lcosts (160) */
+    int32_t label_pitch;         /* LP, elements per pixel in proposals/lcosts (160; multiple of 16) */
     int32_t reserved;
 } dflow_params;
 
@@ -87,9 +87,16 @@ int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, cons
                               uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop,
                               const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream);
 
+/* Builds the compat bit matrices of pakovanje (daisy i flann.py:256-309) into the workspace, in the layout the chain
+ * kernel reads (only the two neighbours a pixel's chains use).  Must be called after the proposals are final (after
+ * dflow_neighbour_proposals / an upload) and before dflow_bcd_phase / dflow_bcd_sweep; the matrices stay valid until
+ * another dflow_* stage call (daisy, knn) reuses the same workspace. */
+int dflow_bcd_prepare(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop,
+                      void *d_ws, size_t ws_bytes, void *stream);
+
 /* One of the four loops of ceoBCD's body, python bcd.py:265-277 (phase 0 even columns top->bottom,
  * 1 even rows right->left, 2 odd columns bottom->top, 3 odd rows left->right); every chain is one call of
- * bcd(), python bcd.py:101-257, with pakovanje's compat test (daisy i flann.py:256-309) evaluated on the fly.
+ * bcd(), python bcd.py:101-257, reading the bit matrices dflow_bcd_prepare left in the workspace.
  * Updates d_bestlabels in place. */
 int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts,
                     const int32_t *d_nprop, int32_t *d_bestlabels, int32_t phase,

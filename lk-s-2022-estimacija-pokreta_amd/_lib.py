@@ -9,7 +9,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdflow.so")
 
 SYMBOLS = ("dflow_version", "dflow_last_error", "dflow_default_params", "dflow_workspace_bytes", "dflow_daisy",
-           "dflow_knn_proposals", "dflow_neighbour_proposals", "dflow_bcd_phase", "dflow_bcd_sweep",
+           "dflow_knn_proposals", "dflow_neighbour_proposals", "dflow_bcd_prepare", "dflow_bcd_phase", "dflow_bcd_sweep",
            "dflow_labels_to_flow", "dflow_fb_consistency")
 
 
@@ -52,6 +52,7 @@ def lib():
         L.dflow_daisy.argtypes = [pp, vp, vp, vp, sz, vp]
         L.dflow_knn_proposals.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.dflow_neighbour_proposals.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.dflow_bcd_prepare.argtypes = [pp, vp, vp, vp, sz, vp]
         L.dflow_bcd_phase.argtypes = [pp, vp, vp, vp, vp, i32, vp, sz, vp]
         L.dflow_bcd_sweep.argtypes = [pp, vp, vp, vp, vp, vp, sz, vp]
         L.dflow_labels_to_flow.argtypes = [pp, vp, vp, vp, vp]

@@ -38,8 +38,8 @@ int dflow_check_params(const dflow_params *p)
     int maxknn = (2 * p->window + 1) * (2 * p->window + 1) * p->knn;
     if (p->maxnprop < maxknn + p->ngauss || p->maxnprop > DFLOW_MAX_LABELS)
         return dflow_set_error(DFLOW_EINVAL, "maxnprop=%d must be in [%d,%d]", p->maxnprop, maxknn + p->ngauss, DFLOW_MAX_LABELS);
-    if (p->label_pitch < p->maxnprop || p->label_pitch % 4 != 0 || p->label_pitch > 256)
-        return dflow_set_error(DFLOW_EINVAL, "label_pitch=%d must be a multiple of 4 in [maxnprop,256]", p->label_pitch);
+    if (p->label_pitch < p->maxnprop || p->label_pitch % 16 != 0 || p->label_pitch > DFLOW_MAX_LABELS)
+        return dflow_set_error(DFLOW_EINVAL, "label_pitch=%d must be a multiple of 16 in [maxnprop,%d]", p->label_pitch, DFLOW_MAX_LABELS);
     if (p->tpsi < 1 || p->tpsi > 4096) return dflow_set_error(DFLOW_EINVAL, "tpsi=%d outside [1,4096]", p->tpsi);
     if (!(p->sigma > 0.0f) || p->sigma > 8.0f) return dflow_set_error(DFLOW_EINVAL, "sigma=%g outside (0,8]", (double)p->sigma);
     if (p->max_attempts < p->ngauss) return dflow_set_error(DFLOW_EINVAL, "max_attempts < ngauss");
@@ -100,6 +100,14 @@ int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, cons
     int rc = dflow_check_params(p); if (rc) return rc;
     CHECK_PTR(d_descr1); CHECK_PTR(d_descr2); CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels);
     return launch_neighbour(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, (hipStream_t)stream);
+}
+
+int dflow_bcd_prepare(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop, void *d_ws, size_t ws_bytes,
+                      void *stream)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_proposals); CHECK_PTR(d_nprop); CHECK_WS(bcd_ws_bytes(p));
+    return launch_bcd_prepare(p, d_proposals, d_nprop, d_ws, (hipStream_t)stream);
 }
 
 int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts, const int32_t *d_nprop,

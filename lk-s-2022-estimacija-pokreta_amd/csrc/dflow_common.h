@@ -99,6 +99,7 @@ int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, ui
 int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop,
                      int32_t *bestlabels, int phase, void *ws, hipStream_t s);
 size_t bcd_ws_bytes(const dflow_params *p);
+int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, void *ws, hipStream_t s);
 int launch_labels_to_flow(const dflow_params *p, const uint32_t *proposals, const int32_t *bestlabels, float *flow,
                           hipStream_t s);
 int launch_fb_consistency(const dflow_params *p, const float *fwd, const float *bwd, float tresh, float *sparse,

@@ -49,6 +49,7 @@ class DiscreteFlow:
         self.ws_bytes = int(_lib.lib().dflow_workspace_bytes(C.byref(self.p)))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self._img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        self._bcd_ready = False     # compat matrices in the workspace are valid for the current proposals
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -72,6 +73,7 @@ class DiscreteFlow:
             img = picture
         if out is None:
             out = torch.empty((H, W, 68), dtype=torch.float32, device=self.device)
+        self._bcd_ready = False
         _lib.check(_lib.lib().dflow_daisy(self._pp(), img.data_ptr(), out.data_ptr(), self.ws.data_ptr(),
                                           self.ws_bytes, self._stream()), "dflow_daisy")
         return out
@@ -87,6 +89,7 @@ class DiscreteFlow:
 
     def generisi(self):
         """napraviCD2 + generisi, daisy i flann.py:144-189."""
+        self._bcd_ready = False
         _lib.check(_lib.lib().dflow_knn_proposals(self._pp(), self.descrs1.data_ptr(), self.descrs2.data_ptr(),
                                                   self.proposals.data_ptr(), self.lcosts.data_ptr(),
                                                   self.nprop.data_ptr(), self.bestlabels.data_ptr(),
@@ -95,20 +98,31 @@ class DiscreteFlow:
 
     def nasumicni(self):
         """daisy i flann.py:205-233."""
+        self._bcd_ready = False
         _lib.check(_lib.lib().dflow_neighbour_proposals(self._pp(), self.descrs1.data_ptr(), self.descrs2.data_ptr(),
                                                         self.proposals.data_ptr(), self.lcosts.data_ptr(),
                                                         self.nprop.data_ptr(), self.bestlabels.data_ptr(),
                                                         self.ws.data_ptr(), self.ws_bytes, self._stream()),
                    "dflow_neighbour_proposals")
 
+    def pakovanje(self):
+        """daisy i flann.py:256-309: compat bit matrices, built into the workspace for the chain kernel."""
+        _lib.check(_lib.lib().dflow_bcd_prepare(self._pp(), self.proposals.data_ptr(), self.nprop.data_ptr(),
+                                                self.ws.data_ptr(), self.ws_bytes, self._stream()), "dflow_bcd_prepare")
+        self._bcd_ready = True
+
     def bcd_phase(self, phase):
         """One of the four chain loops of ceoBCD, python bcd.py:265-277."""
+        if not self._bcd_ready:
+            self.pakovanje()
         _lib.check(_lib.lib().dflow_bcd_phase(self._pp(), self.proposals.data_ptr(), self.lcosts.data_ptr(),
                                               self.nprop.data_ptr(), self.bestlabels.data_ptr(), phase,
                                               self.ws.data_ptr(), self.ws_bytes, self._stream()), "dflow_bcd_phase")
 
     def ceoBCD(self, bcd_times, on_sweep=None):
         """python bcd.py:261-284.  on_sweep(w) is called after sweep w (the reference saves .npy there)."""
+        if not self._bcd_ready:
+            self.pakovanje()
         for w in range(1, bcd_times + 1):
             _lib.check(_lib.lib().dflow_bcd_sweep(self._pp(), self.proposals.data_ptr(), self.lcosts.data_ptr(),
                                                   self.nprop.data_ptr(), self.bestlabels.data_ptr(),
@@ -158,6 +172,7 @@ class DiscreteFlow:
         self.lcosts.copy_(torch.from_numpy(lc))
         self.nprop.copy_(torch.from_numpy(nprop.astype(np.int32)))
         self.bestlabels.copy_(torch.from_numpy(bestlabels.astype(np.int32)))
+        self._bcd_ready = False
 
 
 def fb_consistency(fwd, bwd, tresh, p=None):
