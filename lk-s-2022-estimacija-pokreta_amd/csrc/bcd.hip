@@ -9,15 +9,15 @@
 //                      for the direction in which the chain runs.  lanes = predecessor labels, one v_sad_u16 +
 //                      v_cmp per 64 pairs, the wave ballot is the mask word.
 //   bcd_chain_kernel   one workgroup per chain of a phase (all chains of a phase are independent: a chain reads and
-//                      writes only its own image line).  640 threads = 160 labels x 4 lanes; a lane walks the set
-//                      bits of its quarter of the label's mask row (only compatible predecessors cost float64 work),
-//                      quad DPP merge, float64 arithmetic in the reference's association order
+//                      writes only its own image line).  192 threads, one per label; a lane walks the set bits of
+//                      its label's mask row (only compatible predecessors cost float64 work), float64 arithmetic in
+//                      the reference's association order
 //                      (dp = mincost + ((lamda*lcost + s1) + s2); first-index ties everywhere, Q9-Q11).
 //                      dp / predecessor flows live in LDS (double buffered), label data and mask rows are prefetched
-//                      two steps ahead, back-pointers go to the workspace as uint8 and are walked chunk-wise from LDS.
+//                      three steps ahead, back-pointers go to the workspace as uint8 and are walked chunk-wise from LDS.
 #include "dflow_common.h"
 
-#define BCD_THREADS 640
+#define BCD_THREADS 192
 #define BCD_MASK_WORDS 5                 // 160 bits per label row
 #define BCD_TB_STEPS 128                 // traceback chunk (steps) staged in LDS
 
@@ -47,16 +47,19 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
     if (py < 0 || py >= H || px < 0 || px >= W) return;       // chain start: no transition into this pixel
     const int ppix = py * W + px;
     const int tn = nprop[pix], pn = nprop[ppix];
-    uint32_t fp[3];
+    __shared__ uint32_t stage[4][DFLOW_MAX_LABELS * BCD_MASK_WORDS];
+    uint32_t *st = stage[threadIdx.x >> 6];
+    uint32_t fp[3], fcv[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int k = lane + 64 * j;
         fp[j] = k < pn ? flow_bias(proposals[(size_t)ppix * LP + k]) : 0u;   // 0: far from every biased flow
+        fcv[j] = k < tn ? flow_bias(proposals[(size_t)pix * LP + k]) : 0u;
     }
-    const uint32_t *cur = proposals + (size_t)pix * LP;
-    uint32_t *out = masks + ((size_t)pix * 2 + dir) * (size_t)LP * BCD_MASK_WORDS;
     for (int tl = 0; tl < tn; tl++) {
-        const uint32_t fc = flow_bias(cur[tl]);                 // wave-uniform
+        // label tl of this pixel, broadcast from the lane that holds it (wave-uniform)
+        const uint32_t fsel = tl < 64 ? fcv[0] : (tl < 128 ? fcv[1] : fcv[2]);
+        const uint32_t fc = __builtin_amdgcn_readlane(fsel, tl & 63);
         const unsigned long long m0 = __ballot(flow_l1_biased(fc, fp[0]) < (uint32_t)tpsi);
         const unsigned long long m1 = __ballot(flow_l1_biased(fc, fp[1]) < (uint32_t)tpsi);
         const unsigned long long m2 = __ballot(flow_l1_biased(fc, fp[2]) < (uint32_t)tpsi);
@@ -65,8 +68,11 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
         w = lane == 2 ? (uint32_t)m1 : w;
         w = lane == 3 ? (uint32_t)(m1 >> 32) : w;
         w = lane == 4 ? (uint32_t)m2 : w;
-        if (lane < BCD_MASK_WORDS) out[(size_t)tl * BCD_MASK_WORDS + lane] = w;
+        if (lane < BCD_MASK_WORDS) st[tl * BCD_MASK_WORDS + lane] = w;
     }
+    // one coalesced copy of the tn rows (same wave wrote them: LDS operations of a wave complete in order)
+    uint32_t *out = masks + ((size_t)pix * 2 + dir) * (size_t)LP * BCD_MASK_WORDS;
+    for (int j = lane; j < tn * BCD_MASK_WORDS; j += 64) out[j] = st[j];
 }
 
 // ------------------------------------------------------------------------------------------------ chains
@@ -85,10 +91,12 @@ struct Cand {
     double v; int k;
 };
 
-// (value, index) lexicographic minimum
+// (value, index) lexicographic minimum, branch-free
 __device__ static inline void cand_min(Cand &a, double ov, int ok)
 {
-    if (ov < a.v || (ov == a.v && ok < a.k)) { a.v = ov; a.k = ok; }
+    const bool take = ov < a.v || (ov == a.v && ok < a.k);
+    a.v = take ? ov : a.v;
+    a.k = take ? ok : a.k;
 }
 
 template <int CTRL> __device__ static inline void cand_dpp(const Cand &a, double &ov, int &ok)
@@ -101,40 +109,45 @@ template <int CTRL> __device__ static inline void cand_dpp(const Cand &a, double
     ov = __hiloint2double(ohi, olo);
 }
 
-#define DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
-#define DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define DPP_ROW_SHL1 0x101
+#define DPP_ROW_SHL2 0x102
 #define DPP_ROW_SHL4 0x104
 #define DPP_ROW_SHL8 0x108
 
-
-// minimum over the 16 label owners of a wave (lanes 0,4,..,60), valid in lane 0
-__device__ static inline void wave_owner_min(Cand &pm)
+// lexicographic minimum over the 64 lanes of a wave, valid in lane 0
+__device__ static inline void wave_min_lane0(Cand &pm)
 {
     double ov; int ok;
+    cand_dpp<DPP_ROW_SHL1>(pm, ov, ok); cand_min(pm, ov, ok);
+    cand_dpp<DPP_ROW_SHL2>(pm, ov, ok); cand_min(pm, ov, ok);
     cand_dpp<DPP_ROW_SHL4>(pm, ov, ok); cand_min(pm, ov, ok);
     cand_dpp<DPP_ROW_SHL8>(pm, ov, ok); cand_min(pm, ov, ok);
     const int lo = __double2loint(pm.v), hi = __double2hiint(pm.v);
 #pragma unroll
-    for (int r = 1; r < 4; r++) {    // rows are in label order: merging row leaders 16, 32, 48 into lane 0 keeps first-index ties
+    for (int r = 1; r < 4; r++) {
         const double rv = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
         const int rk = __builtin_amdgcn_readlane(pm.k, 16 * r);
         cand_min(pm, rv, rk);
     }
 }
 
+// One thread per label: 192 threads (3 waves) cover up to DFLOW_MAX_LABELS labels.  Few, busy threads keep the
+// per-step instruction count (and with it the latency of the serial chain) low.
 __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *dpbuf = (double *)smem;                                   // [2][DFLOW_MAX_LABELS]
-    double *permv = dpbuf + 2 * DFLOW_MAX_LABELS;                     // [2][16] per-wave minima of tpsi + dp
-    uint32_t *fpbuf = (uint32_t *)(permv + 2 * 16);                   // [2][DFLOW_MAX_LABELS] biased flows
-    int *permi = (int *)(fpbuf + 2 * DFLOW_MAX_LABELS);               // [2][16]; permi[32] = traceback hand-over
-    uint8_t *tb = (uint8_t *)(permi + 2 * 16 + 4);                    // [BCD_TB_STEPS][LP] traceback chunk (16-byte aligned)
+    double *permv = dpbuf + 2 * DFLOW_MAX_LABELS;                     // [2][4] per-wave minima of tpsi + dp
+    uint32_t *fpbuf = (uint32_t *)(permv + 2 * 4);                    // [2][DFLOW_MAX_LABELS] biased flows
+    int *permi = (int *)(fpbuf + 2 * DFLOW_MAX_LABELS);               // [2][4]; permi[8] = traceback hand-over
+    uint8_t *tb = (uint8_t *)(permi + 2 * 4 + 4);                     // [BCD_TB_STEPS][LP] traceback chunk (16-byte aligned)
     uint32_t *bestf = (uint32_t *)(tb + BCD_TB_STEPS * a.LP);         // [len] biased flow of each chain pixel's current label
-    int *s_label = permi + 32;
+    int *tnl;                                                         // [len] nprop of each chain pixel (set below)
+    int *s_label = permi + 8;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tl = tid >> 2, part = tid & 3;
+    const int tl = tid < DFLOW_MAX_LABELS ? tid : DFLOW_MAX_LABELS - 1;   // threads 160..191 shadow the last label row and never write
+    const bool owner = tid < DFLOW_MAX_LABELS;
     const int nwaves = BCD_THREADS / 64;
     const int chain = blockIdx.x;
     const int W = a.W, LP = a.LP;
@@ -149,31 +162,29 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     const uint32_t tpsi = (uint32_t)a.tpsi;
     const double tpsi_d = (double)a.tpsi;
 
+    tnl = (int *)(bestf + len);
     for (int i = tid; i < len; i += BCD_THREADS) {
         int pix = pix0 + i * pstep;
         bestf[i] = flow_bias(a.proposals[(size_t)pix * LP + a.bestlabels[pix]]);
+        tnl[i] = a.nprop[pix];      // a wave-uniform global load inside the step loop would stall every step (it is
+                                    // moved to an SGPR at once); the label counts are read from LDS instead
     }
     __syncthreads();
 
     uint8_t *back = a.back + (size_t)chain * len * LP;
 
-    // per-step inputs of this thread, prefetched three steps ahead (A = next step, B, C)
-    struct StepIn { int tn; uint32_t F; float lc; uint32_t mw, m4; };
+    // Per-step inputs of this thread, prefetched three steps ahead.  All loads are unconditional (rows are LP wide;
+    // mask rows of unused labels hold garbage that is masked at use), so nothing in a step waits for a load issued
+    // in the same step.
+    struct StepIn { uint32_t F; float lc; uint32_t m[BCD_MASK_WORDS]; };
     auto fetch = [&](int i) {
-        StepIn r; r.tn = 0; r.F = 0; r.lc = 0.0f; r.mw = 0; r.m4 = 0;
-        if (i < len) {
-            const int pix = pix0 + i * pstep;
-            r.tn = a.nprop[pix];
-            if (tl < r.tn) {
-                r.F = flow_bias(a.proposals[(size_t)pix * LP + tl]);
-                r.lc = a.lcosts[(size_t)pix * LP + tl];
-                if (i > 0) {
-                    const uint32_t *row = a.masks + (((size_t)pix * 2 + dir) * LP + tl) * BCD_MASK_WORDS;
-                    r.mw = row[part];
-                    r.m4 = (row[4] >> (8 * part)) & 0xFFu;
-                }
-            }
-        }
+        StepIn r;
+        const int pix = pix0 + min(i, len - 1) * pstep;
+        r.F = flow_bias(a.proposals[(size_t)pix * LP + tl]);
+        r.lc = a.lcosts[(size_t)pix * LP + tl];
+        const uint32_t *row = a.masks + (((size_t)pix * 2 + dir) * LP + tl) * BCD_MASK_WORDS;
+#pragma unroll
+        for (int j = 0; j < BCD_MASK_WORDS; j++) r.m[j] = row[j];
         return r;
     };
     const StepIn S0 = fetch(0);
@@ -181,77 +192,85 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
 
     // ---- chain start: dp[0,tl] = (s1 + s2) + lamda*lcost   (python bcd.py:118-120)
     {
-        const int tn = S0.tn;
         const uint32_t Fc = S0.F;
         const int ip = dirp, im = -dirp;
         const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
         const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
         Cand pm; pm.v = 1e300; pm.k = 0x7fffffff;
-        if (part == 0 && tl < tn) {
+        if (owner && tl < tnl[0]) {
             const double d0 = __dadd_rn((double)(s1 + s2), __dmul_rn(a.lamda, (double)S0.lc));
             dpbuf[tl] = d0;
             fpbuf[tl] = Fc;
             pm.v = __dadd_rn(tpsi_d, d0); pm.k = tl;
         }
-        wave_owner_min(pm);
+        wave_min_lane0(pm);
         if (lane == 0) { permv[wave] = pm.v; permi[wave] = pm.k; }
     }
     __syncthreads();
 
     int cur = 1;
-    int pn = S0.tn;
-    for (int i = 1; i < len; i++) {
-        const int tn = A.tn;
-        const uint32_t Fc = A.F;
-        const float lc = A.lc;
-        uint32_t mw = A.mw, m4 = A.m4;
-        A = B; B = C; C = fetch(i + 3);
+    int pn = tnl[0];
+    // One step of the chain.  `in` is consumed first and then refilled with the inputs of step i+3: the three slots are
+    // used round-robin by the 3x unrolled loop below, so prefetched registers are never copied while their loads are
+    // still in flight (a register rotation A=B, B=C would make every step wait for the loads it has just issued).
+    auto step = [&](const int i, StepIn &in) __attribute__((always_inline)) {
+        const int tn = tnl[i];
+        const uint32_t Fc = in.F;
+        const float lc = in.lc;
+        const bool act = owner && tl < tn;
+        unsigned long long w0 = act ? ((unsigned long long)in.m[0] | ((unsigned long long)in.m[1] << 32)) : 0ull;
+        unsigned long long w1 = act ? ((unsigned long long)in.m[2] | ((unsigned long long)in.m[3] << 32)) : 0ull;
+        unsigned long long w2 = act ? (unsigned long long)in.m[4] : 0ull;
+        in = fetch(i + 3);
         const double *dp = dpbuf + (cur ^ 1) * DFLOW_MAX_LABELS;
         const uint32_t *fp = fpbuf + (cur ^ 1) * DFLOW_MAX_LABELS;
 
+        // min over compatible previous labels (python bcd.py:163-176 / :198-219): walk the set bits of my mask row in
+        // increasing k (strict '<' keeps the first minimum); the LDS reads of the next candidate are issued before the
+        // current one is evaluated
+        double bestv = 1e300; int bestk = 0x7fffffff;
+        {
+            // Up to four set bits are extracted per round and their LDS reads issued together, so the read latency is
+            // paid once per round instead of once per candidate.  Candidates are evaluated in increasing k.
+            int base = 0;
+            auto next_bit = [&](bool &valid) {
+                if (w0 == 0) { w0 = w1; w1 = w2; w2 = 0; base += 64; if (w0 == 0) { w0 = w1; w1 = 0; base += 64; } }
+                valid = w0 != 0;
+                int k = 0;
+                if (valid) { k = base + __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
+                return k;
+            };
+            while (w0 | w1 | w2) {
+                bool v0, v1, v2, v3;
+                const int k0 = next_bit(v0), k1 = next_bit(v1), k2 = next_bit(v2), k3 = next_bit(v3);
+                const double d0 = dp[k0], d1 = dp[k1], d2 = dp[k2], d3 = dp[k3];     // invalid slots read label 0: harmless
+                const uint32_t f0 = fp[k0], f1 = fp[k1], f2 = fp[k2], f3 = fp[k3];
+                const double c0 = __dadd_rn(d0, (double)flow_l1_biased(Fc, f0));
+                const double c1 = __dadd_rn(d1, (double)flow_l1_biased(Fc, f1));
+                const double c2 = __dadd_rn(d2, (double)flow_l1_biased(Fc, f2));
+                const double c3 = __dadd_rn(d3, (double)flow_l1_biased(Fc, f3));
+                bool t;
+                t = v0 && c0 < bestv; bestv = t ? c0 : bestv; bestk = t ? k0 : bestk;
+                t = v1 && c1 < bestv; bestv = t ? c1 : bestv; bestk = t ? k1 : bestk;
+                t = v2 && c2 < bestv; bestv = t ? c2 : bestv; bestk = t ? k2 : bestk;
+                t = v3 && c3 < bestv; bestv = t ? c3 : bestv; bestk = t ? k3 : bestk;
+            }
+        }
         // permmincost / permminlabel (python bcd.py:152-157): first minimum of tpsi + dp[k] over the previous labels,
-        // merged from the per-row minima the previous step left in LDS (rows are in label order)
+        // merged from the per-wave minima the previous step left in LDS (waves are in label order)
         Cand perm; perm.v = 800000.0; perm.k = 0x7fffffff;
-        {
-            const double *pv = permv + (cur ^ 1) * 16;
-            const int *pi = permi + (cur ^ 1) * 16;
-            for (int w = 0; w < nwaves; w++) {
-                if (w * 16 >= pn) break;
-                cand_min(perm, pv[w], pi[w]);
-            }
-        }
+#pragma unroll
+        for (int w = 0; w < nwaves; w++)
+            if (w * 64 < pn) cand_min(perm, permv[(cur ^ 1) * 4 + w], permi[(cur ^ 1) * 4 + w]);
 
-        // min over compatible previous labels (python bcd.py:163-176 / :198-219): walk the set bits of my quarter
-        Cand best; best.v = 1e300; best.k = 0x7fffffff;
-        {
-            const int kb = 32 * part;
-            while (mw) {
-                const int b = __ffs(mw) - 1; mw &= mw - 1;
-                const int k = kb + b;
-                const uint32_t psi = flow_l1_biased(Fc, fp[k]);
-                cand_min(best, __dadd_rn(dp[k], (double)psi), k);
-            }
-            const int kb4 = 128 + 8 * part;
-            while (m4) {
-                const int b = __ffs(m4) - 1; m4 &= m4 - 1;
-                const int k = kb4 + b;
-                const uint32_t psi = flow_l1_biased(Fc, fp[k]);
-                cand_min(best, __dadd_rn(dp[k], (double)psi), k);
-            }
-        }
-        {
-            double ov; int ok;
-            cand_dpp<DPP_QUAD_XOR1>(best, ov, ok); cand_min(best, ov, ok);
-            cand_dpp<DPP_QUAD_XOR2>(best, ov, ok); cand_min(best, ov, ok);
-        }
         Cand pm; pm.v = 1e300; pm.k = 0x7fffffff;
-        if (part == 0 && tl < tn) {
+        if (act) {
             const int ip = i + dirp, im = i - dirp;
             const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
             const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
-            const bool found = best.k != 0x7fffffff;
-            const double mincost = found ? best.v : perm.v;
-            const int pl = found ? best.k : perm.k;
+            const bool found = bestk != 0x7fffffff;
+            const double mincost = found ? bestv : perm.v;
+            const int pl = found ? bestk : perm.k;
             const double small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
             const double dpc = __dadd_rn(mincost, small);
             dpbuf[cur * DFLOW_MAX_LABELS + tl] = dpc;
@@ -259,11 +278,20 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
             back[(size_t)i * LP + tl] = (uint8_t)pl;
             pm.v = __dadd_rn(tpsi_d, dpc); pm.k = tl;
         }
-        wave_owner_min(pm);
-        if (lane == 0) { permv[cur * 16 + wave] = pm.v; permi[cur * 16 + wave] = pm.k; }
-        __syncthreads();
+        wave_min_lane0(pm);
+        if (lane == 0) { permv[cur * 4 + wave] = pm.v; permi[cur * 4 + wave] = pm.k; }
+        // LDS-only barrier: __syncthreads() would also wait for the global prefetches issued in this step (vmcnt(0)) and
+        // put their full latency on every step of the chain
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         pn = tn;
         cur ^= 1;
+    };
+    for (int i = 1; i < len; i += 3) {
+        step(i, A);
+        if (i + 1 < len) step(i + 1, B);
+        if (i + 2 < len) step(i + 2, C);
     }
 
     // ---- end label: first minimum of dp[len-1] (python bcd.py:231-237): tpsi + dp is monotone in dp, but two different
@@ -272,12 +300,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         const double *dp = dpbuf + (cur ^ 1) * DFLOW_MAX_LABELS;
         Cand m; m.v = 800000.0; m.k = 0x7fffffff;
         for (int k = lane; k < pn; k += 64) { double c = dp[k]; if (c < m.v) { m.v = c; m.k = k; } }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            double ov = __shfl_xor(m.v, off);
-            int ok = __shfl_xor(m.k, off);
-            cand_min(m, ov, ok);
-        }
+        wave_min_lane0(m);
         if (tid == 0) *s_label = m.k == 0x7fffffff ? 0 : m.k;
     }
     __syncthreads();
@@ -349,8 +372,8 @@ int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const flo
     a.H = p->pich; a.W = p->picw; a.LP = p->label_pitch; a.tpsi = p->tpsi; a.phase = phase; a.lamda = p->lamda;
     a.proposals = proposals; a.lcosts = lcosts; a.nprop = nprop; a.bestlabels = bestlabels;
     a.back = (uint8_t *)ws; a.masks = (const uint32_t *)((char *)ws + back_bytes(p));
-    size_t shmem = 2 * DFLOW_MAX_LABELS * (sizeof(double) + sizeof(uint32_t)) + 2 * 16 * (sizeof(double) + sizeof(int)) + 16 +
-                   (size_t)BCD_TB_STEPS * p->label_pitch + (size_t)len * sizeof(uint32_t);
+    size_t shmem = 2 * DFLOW_MAX_LABELS * (sizeof(double) + sizeof(uint32_t)) + 2 * 4 * (sizeof(double) + sizeof(int)) + 16 +
+                   (size_t)BCD_TB_STEPS * p->label_pitch + (size_t)len * (sizeof(uint32_t) + sizeof(int));
     hipLaunchKernelGGL(bcd_chain_kernel, dim3(nchains), dim3(BCD_THREADS), shmem, s, a);
     return dflow_check_launch("bcd_chain_kernel");
 }
