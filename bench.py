@@ -160,7 +160,10 @@ def main():
                        "parallelism": "one pass per step; %d independent steps in flight per GPU on separate HIP streams; "
                                       "flow fields gathered on rank 0" % P},
             "roofline": {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # FETCH_SIZE + WRITE_SIZE per launch, rocprofv3 --pmc (one counter per pass, raw values,
+                         # profiles/r01_pmc_traffic.txt); expected from the access pattern: 0.94 GB (labels + bit rows)
+                         "traffic": (526595 + 33636) * 1024,
                          "launch_ms": bcd_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "serial Viterbi chains (218-512 workgroups x 436-1024 dependent steps): latency-bound, "
                                  "not bandwidth-bound; launch_ms is measured with %d pairs in flight" % P},
