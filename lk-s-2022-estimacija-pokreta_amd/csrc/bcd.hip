@@ -19,6 +19,9 @@
 
 #define BCD_THREADS 192
 #define BCD_MASK_WORDS 5                 // 160 bits per label row
+#define BCD_ROW_WORDS 8                  // one row record: 5 mask words, 2 words = first 8 set bits as bytes (0xFF = none), 1 word = popcount
+#define BCD_LIST 8
+#define BCD_LDS_LABELS 256
 #define BCD_TB_STEPS 128                 // traceback chunk (steps) staged in LDS
 
 __device__ static inline void chain_geom(int phase, int chain, int H, int W, int &ty, int &tx, int &ys, int &xs, int &len)
@@ -47,7 +50,7 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
     if (py < 0 || py >= H || px < 0 || px >= W) return;       // chain start: no transition into this pixel
     const int ppix = py * W + px;
     const int tn = nprop[pix], pn = nprop[ppix];
-    __shared__ uint32_t stage[4][DFLOW_MAX_LABELS * BCD_MASK_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[4][DFLOW_MAX_LABELS * BCD_ROW_WORDS];
     uint32_t *st = stage[threadIdx.x >> 6];
     uint32_t fp[3], fcv[3];
 #pragma unroll
@@ -68,11 +71,33 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
         w = lane == 2 ? (uint32_t)m1 : w;
         w = lane == 3 ? (uint32_t)(m1 >> 32) : w;
         w = lane == 4 ? (uint32_t)m2 : w;
-        if (lane < BCD_MASK_WORDS) st[tl * BCD_MASK_WORDS + lane] = w;
+        if (lane < BCD_MASK_WORDS) st[tl * BCD_ROW_WORDS + lane] = w;
     }
-    // one coalesced copy of the tn rows (same wave wrote them: LDS operations of a wave complete in order)
-    uint32_t *out = masks + ((size_t)pix * 2 + dir) * (size_t)LP * BCD_MASK_WORDS;
-    for (int j = lane; j < tn * BCD_MASK_WORDS; j += 64) out[j] = st[j];
+    // second half, lanes = rows: the first 8 set bits of every row as a byte list (what the chain kernel reads in the
+    // common case) and the row's popcount (same wave wrote the masks: LDS operations of a wave complete in order)
+    for (int tl = lane; tl < tn; tl += 64) {
+        uint32_t m[BCD_MASK_WORDS];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < BCD_MASK_WORDS; j++) { m[j] = st[tl * BCD_ROW_WORDS + j]; cnt += __popc(m[j]); }
+        uint32_t l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu;
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < BCD_MASK_WORDS; j++) {
+            uint32_t w = m[j];
+            while (w && n < BCD_LIST) {
+                const uint32_t k = 32 * j + __ffs(w) - 1; w &= w - 1;
+                if (n < 4) l0 = (l0 & ~(0xFFu << (8 * n))) | (k << (8 * n));
+                else l1 = (l1 & ~(0xFFu << (8 * (n - 4)))) | (k << (8 * (n - 4)));
+                n++;
+            }
+        }
+        st[tl * BCD_ROW_WORDS + 5] = l0; st[tl * BCD_ROW_WORDS + 6] = l1; st[tl * BCD_ROW_WORDS + 7] = (uint32_t)cnt;
+    }
+    // one coalesced copy of the tn row records
+    uint4 *out = reinterpret_cast<uint4 *>(masks + ((size_t)pix * 2 + dir) * (size_t)LP * BCD_ROW_WORDS);
+    const uint4 *src = reinterpret_cast<const uint4 *>(st);
+    for (int j = lane; j < tn * (BCD_ROW_WORDS / 4); j += 64) out[j] = src[j];
 }
 
 // ------------------------------------------------------------------------------------------------ chains
@@ -131,15 +156,47 @@ __device__ static inline void wave_min_lane0(Cand &pm)
     }
 }
 
+
+// Minimum of a 64-bit key over the wave (keys = bit patterns of positive doubles, which order like the doubles) and
+// the first lane that attains it: 4 DPP steps inside the rows of 16 lanes, the row leaders through v_readlane, then
+// one ballot.  Returns the minimum in every lane, *first_lane likewise.
+template <int CTRL> __device__ static inline unsigned long long key_dpp_min(unsigned long long x)
+{
+    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < x ? o : x;
+}
+__device__ static inline unsigned long long wave_key_min(unsigned long long key, int *first_lane)
+{
+    unsigned long long x = key;
+    x = key_dpp_min<DPP_ROW_SHL1>(x);
+    x = key_dpp_min<DPP_ROW_SHL2>(x);
+    x = key_dpp_min<DPP_ROW_SHL4>(x);
+    x = key_dpp_min<DPP_ROW_SHL8>(x);
+    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
+    unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, 0) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, 0);
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, 16 * r) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane(lo, 16 * r);
+        m = o < m ? o : m;
+    }
+    const unsigned long long hit = __ballot(key == m);
+    *first_lane = __ffsll((long long)hit) - 1;
+    return m;
+}
+
 // One thread per label: 192 threads (3 waves) cover up to DFLOW_MAX_LABELS labels.  Few, busy threads keep the
 // per-step instruction count (and with it the latency of the serial chain) low.
 __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *dpbuf = (double *)smem;                                   // [2][DFLOW_MAX_LABELS]
-    double *permv = dpbuf + 2 * DFLOW_MAX_LABELS;                     // [2][4] per-wave minima of tpsi + dp
-    uint32_t *fpbuf = (uint32_t *)(permv + 2 * 4);                    // [2][DFLOW_MAX_LABELS] biased flows
-    int *permi = (int *)(fpbuf + 2 * DFLOW_MAX_LABELS);               // [2][4]; permi[8] = traceback hand-over
+    double *dpbuf = (double *)smem;                                   // [2][BCD_LDS_LABELS]; entries >= 160 stay +inf (list sentinel 0xFF)
+    unsigned long long *permv = (unsigned long long *)(dpbuf + 2 * BCD_LDS_LABELS);   // [2][4] per-wave minima of bits(tpsi + dp)
+    uint32_t *fpbuf = (uint32_t *)(permv + 2 * 4);                    // [2][BCD_LDS_LABELS] biased flows
+    int *permi = (int *)(fpbuf + 2 * BCD_LDS_LABELS);               // [2][4]; permi[8] = traceback hand-over
     uint8_t *tb = (uint8_t *)(permi + 2 * 4 + 4);                     // [BCD_TB_STEPS][LP] traceback chunk (16-byte aligned)
     uint32_t *bestf = (uint32_t *)(tb + BCD_TB_STEPS * a.LP);         // [len] biased flow of each chain pixel's current label
     int *tnl;                                                         // [len] nprop of each chain pixel (set below)
@@ -148,7 +205,6 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tl = tid < DFLOW_MAX_LABELS ? tid : DFLOW_MAX_LABELS - 1;   // threads 160..191 shadow the last label row and never write
     const bool owner = tid < DFLOW_MAX_LABELS;
-    const int nwaves = BCD_THREADS / 64;
     const int chain = blockIdx.x;
     const int W = a.W, LP = a.LP;
     int ty0, tx0, ys, xs, len;
@@ -163,6 +219,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     const double tpsi_d = (double)a.tpsi;
 
     tnl = (int *)(bestf + len);
+    for (int i = tid; i < 2 * BCD_LDS_LABELS; i += BCD_THREADS) { dpbuf[i] = 1e300; fpbuf[i] = 0u; }
     for (int i = tid; i < len; i += BCD_THREADS) {
         int pix = pix0 + i * pstep;
         bestf[i] = flow_bias(a.proposals[(size_t)pix * LP + a.bestlabels[pix]]);
@@ -176,15 +233,14 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     // Per-step inputs of this thread, prefetched three steps ahead.  All loads are unconditional (rows are LP wide;
     // mask rows of unused labels hold garbage that is masked at use), so nothing in a step waits for a load issued
     // in the same step.
-    struct StepIn { uint32_t F; float lc; uint32_t m[BCD_MASK_WORDS]; };
+    struct StepIn { uint32_t F; float lc; uint4 ra, rb; };   // ra = mask words 0..3, rb = {mask word 4, list 0..3, list 4..7, popcount}
     auto fetch = [&](int i) {
         StepIn r;
         const int pix = pix0 + min(i, len - 1) * pstep;
         r.F = flow_bias(a.proposals[(size_t)pix * LP + tl]);
         r.lc = a.lcosts[(size_t)pix * LP + tl];
-        const uint32_t *row = a.masks + (((size_t)pix * 2 + dir) * LP + tl) * BCD_MASK_WORDS;
-#pragma unroll
-        for (int j = 0; j < BCD_MASK_WORDS; j++) r.m[j] = row[j];
+        const uint4 *row = reinterpret_cast<const uint4 *>(a.masks + (((size_t)pix * 2 + dir) * LP + tl) * BCD_ROW_WORDS);
+        r.ra = row[0]; r.rb = row[1];
         return r;
     };
     const StepIn S0 = fetch(0);
@@ -196,15 +252,16 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         const int ip = dirp, im = -dirp;
         const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
         const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
-        Cand pm; pm.v = 1e300; pm.k = 0x7fffffff;
+        unsigned long long key = ~0ull;
         if (owner && tl < tnl[0]) {
             const double d0 = __dadd_rn((double)(s1 + s2), __dmul_rn(a.lamda, (double)S0.lc));
             dpbuf[tl] = d0;
             fpbuf[tl] = Fc;
-            pm.v = __dadd_rn(tpsi_d, d0); pm.k = tl;
+            key = (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, d0));
         }
-        wave_min_lane0(pm);
-        if (lane == 0) { permv[wave] = pm.v; permi[wave] = pm.k; }
+        int fl;
+        const unsigned long long m = wave_key_min(key, &fl);
+        if (lane == 0) { permv[wave] = m; permi[wave] = wave * 64 + fl; }
     }
     __syncthreads();
 
@@ -218,20 +275,37 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         const uint32_t Fc = in.F;
         const float lc = in.lc;
         const bool act = owner && tl < tn;
-        unsigned long long w0 = act ? ((unsigned long long)in.m[0] | ((unsigned long long)in.m[1] << 32)) : 0ull;
-        unsigned long long w1 = act ? ((unsigned long long)in.m[2] | ((unsigned long long)in.m[3] << 32)) : 0ull;
-        unsigned long long w2 = act ? (unsigned long long)in.m[4] : 0ull;
+        const uint4 ra = in.ra, rb = in.rb;
         in = fetch(i + 3);
-        const double *dp = dpbuf + (cur ^ 1) * DFLOW_MAX_LABELS;
-        const uint32_t *fp = fpbuf + (cur ^ 1) * DFLOW_MAX_LABELS;
+        const double *dp = dpbuf + (cur ^ 1) * BCD_LDS_LABELS;
+        const uint32_t *fp = fpbuf + (cur ^ 1) * BCD_LDS_LABELS;
 
         // min over compatible previous labels (python bcd.py:163-176 / :198-219): walk the set bits of my mask row in
         // increasing k (strict '<' keeps the first minimum); the LDS reads of the next candidate are issued before the
         // current one is evaluated
         double bestv = 1e300; int bestk = 0x7fffffff;
-        {
-            // Up to four set bits are extracted per round and their LDS reads issued together, so the read latency is
-            // paid once per round instead of once per candidate.  Candidates are evaluated in increasing k.
+        const int cnt = act ? (int)rb.w : 0;
+        if (__ballot(cnt > BCD_LIST) == 0) {
+            // common case: every row of this wave has at most 8 compatible predecessors; their indices come as a byte
+            // list in increasing k (0xFF = none, which reads the +inf tail of dp), all 16 LDS reads are issued together
+            const uint32_t l0 = act ? rb.y : 0xFFFFFFFFu, l1 = act ? rb.z : 0xFFFFFFFFu;
+            int kk[BCD_LIST]; double dd[BCD_LIST]; uint32_t ff[BCD_LIST];
+#pragma unroll
+            for (int j = 0; j < BCD_LIST; j++) {
+                kk[j] = (int)(((j < 4 ? l0 : l1) >> (8 * (j & 3))) & 0xFFu);
+                dd[j] = dp[kk[j]]; ff[j] = fp[kk[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < BCD_LIST; j++) {
+                const double c = __dadd_rn(dd[j], (double)flow_l1_biased(Fc, ff[j]));
+                const bool t = c < bestv;               // +inf + psi = +inf never wins
+                bestv = t ? c : bestv; bestk = t ? kk[j] : bestk;
+            }
+        } else {
+            // some row is denser: walk the full 160-bit rows, four set bits per round (their LDS reads issued together)
+            unsigned long long w0 = act ? ((unsigned long long)ra.x | ((unsigned long long)ra.y << 32)) : 0ull;
+            unsigned long long w1 = act ? ((unsigned long long)ra.z | ((unsigned long long)ra.w << 32)) : 0ull;
+            unsigned long long w2 = act ? (unsigned long long)rb.x : 0ull;
             int base = 0;
             auto next_bit = [&](bool &valid) {
                 if (w0 == 0) { w0 = w1; w1 = w2; w2 = 0; base += 64; if (w0 == 0) { w0 = w1; w1 = 0; base += 64; } }
@@ -258,12 +332,18 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         }
         // permmincost / permminlabel (python bcd.py:152-157): first minimum of tpsi + dp[k] over the previous labels,
         // merged from the per-wave minima the previous step left in LDS (waves are in label order)
-        Cand perm; perm.v = 800000.0; perm.k = 0x7fffffff;
-#pragma unroll
-        for (int w = 0; w < nwaves; w++)
-            if (w * 64 < pn) cand_min(perm, permv[(cur ^ 1) * 4 + w], permi[(cur ^ 1) * 4 + w]);
+        // waves are in label order and every partial index is the first one inside its wave
+        Cand perm;
+        {
+            const unsigned long long p0 = permv[(cur ^ 1) * 4], p1 = permv[(cur ^ 1) * 4 + 1], p2 = permv[(cur ^ 1) * 4 + 2];
+            const int i0 = permi[(cur ^ 1) * 4], i1 = permi[(cur ^ 1) * 4 + 1], i2 = permi[(cur ^ 1) * 4 + 2];
+            unsigned long long pmn = p0; int pix_ = i0;
+            if (p1 < pmn) { pmn = p1; pix_ = i1; }
+            if (p2 < pmn) { pmn = p2; pix_ = i2; }
+            perm.v = __longlong_as_double((long long)pmn); perm.k = pix_;
+        }
 
-        Cand pm; pm.v = 1e300; pm.k = 0x7fffffff;
+        unsigned long long key = ~0ull;
         if (act) {
             const int ip = i + dirp, im = i - dirp;
             const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
@@ -273,13 +353,16 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
             const int pl = found ? bestk : perm.k;
             const double small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
             const double dpc = __dadd_rn(mincost, small);
-            dpbuf[cur * DFLOW_MAX_LABELS + tl] = dpc;
-            fpbuf[cur * DFLOW_MAX_LABELS + tl] = Fc;
+            dpbuf[cur * BCD_LDS_LABELS + tl] = dpc;
+            fpbuf[cur * BCD_LDS_LABELS + tl] = Fc;
             back[(size_t)i * LP + tl] = (uint8_t)pl;
-            pm.v = __dadd_rn(tpsi_d, dpc); pm.k = tl;
+            key = (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, dpc));
         }
-        wave_min_lane0(pm);
-        if (lane == 0) { permv[cur * 4 + wave] = pm.v; permi[cur * 4 + wave] = pm.k; }
+        {
+            int fl;
+            const unsigned long long m = wave_key_min(key, &fl);
+            if (lane == 0) { permv[cur * 4 + wave] = m; permi[cur * 4 + wave] = wave * 64 + fl; }
+        }
         // LDS-only barrier: __syncthreads() would also wait for the global prefetches issued in this step (vmcnt(0)) and
         // put their full latency on every step of the chain
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -297,7 +380,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     // ---- end label: first minimum of dp[len-1] (python bcd.py:231-237): tpsi + dp is monotone in dp, but two different
     // dp may round to the same sum, so the minimum is taken over dp itself
     if (tid < 64) {
-        const double *dp = dpbuf + (cur ^ 1) * DFLOW_MAX_LABELS;
+        const double *dp = dpbuf + (cur ^ 1) * BCD_LDS_LABELS;
         Cand m; m.v = 800000.0; m.k = 0x7fffffff;
         for (int k = lane; k < pn; k += 64) { double c = dp[k]; if (c < m.v) { m.v = c; m.k = k; } }
         wave_min_lane0(m);
@@ -348,7 +431,7 @@ static size_t back_bytes(const dflow_params *p)
 
 static size_t mask_bytes(const dflow_params *p)
 {
-    return (size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_MASK_WORDS * sizeof(uint32_t);
+    return (size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_ROW_WORDS * sizeof(uint32_t);
 }
 
 size_t bcd_ws_bytes(const dflow_params *p) { return back_bytes(p) + mask_bytes(p); }
@@ -372,7 +455,7 @@ int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const flo
     a.H = p->pich; a.W = p->picw; a.LP = p->label_pitch; a.tpsi = p->tpsi; a.phase = phase; a.lamda = p->lamda;
     a.proposals = proposals; a.lcosts = lcosts; a.nprop = nprop; a.bestlabels = bestlabels;
     a.back = (uint8_t *)ws; a.masks = (const uint32_t *)((char *)ws + back_bytes(p));
-    size_t shmem = 2 * DFLOW_MAX_LABELS * (sizeof(double) + sizeof(uint32_t)) + 2 * 4 * (sizeof(double) + sizeof(int)) + 16 +
+    size_t shmem = 2 * 256 * (sizeof(double) + sizeof(uint32_t)) + 2 * 4 * (sizeof(double) + sizeof(int)) + 16 +
                    (size_t)BCD_TB_STEPS * p->label_pitch + (size_t)len * (sizeof(uint32_t) + sizeof(int));
     hipLaunchKernelGGL(bcd_chain_kernel, dim3(nchains), dim3(BCD_THREADS), shmem, s, a);
     return dflow_check_launch("bcd_chain_kernel");
