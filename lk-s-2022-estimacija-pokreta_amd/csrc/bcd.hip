@@ -285,9 +285,9 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         // current one is evaluated
         double bestv = 1e300; int bestk = 0x7fffffff;
         const int cnt = act ? (int)rb.w : 0;
-        if (__ballot(cnt > BCD_LIST) == 0) {
-            // common case: every row of this wave has at most 8 compatible predecessors; their indices come as a byte
-            // list in increasing k (0xFF = none, which reads the +inf tail of dp), all 16 LDS reads are issued together
+        {
+            // The first 8 compatible predecessors of every row come as a byte list in increasing k (0xFF = none, which
+            // reads the +inf tail of dp); all 16 LDS reads are issued together.
             const uint32_t l0 = act ? rb.y : 0xFFFFFFFFu, l1 = act ? rb.z : 0xFFFFFFFFu;
             int kk[BCD_LIST]; double dd[BCD_LIST]; uint32_t ff[BCD_LIST];
 #pragma unroll
@@ -301,33 +301,42 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
                 const bool t = c < bestv;               // +inf + psi = +inf never wins
                 bestv = t ? c : bestv; bestk = t ? kk[j] : bestk;
             }
-        } else {
-            // some row is denser: walk the full 160-bit rows, four set bits per round (their LDS reads issued together)
-            unsigned long long w0 = act ? ((unsigned long long)ra.x | ((unsigned long long)ra.y << 32)) : 0ull;
-            unsigned long long w1 = act ? ((unsigned long long)ra.z | ((unsigned long long)ra.w << 32)) : 0ull;
-            unsigned long long w2 = act ? (unsigned long long)rb.x : 0ull;
-            int base = 0;
-            auto next_bit = [&](bool &valid) {
-                if (w0 == 0) { w0 = w1; w1 = w2; w2 = 0; base += 64; if (w0 == 0) { w0 = w1; w1 = 0; base += 64; } }
-                valid = w0 != 0;
-                int k = 0;
-                if (valid) { k = base + __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
-                return k;
-            };
-            while (w0 | w1 | w2) {
-                bool v0, v1, v2, v3;
-                const int k0 = next_bit(v0), k1 = next_bit(v1), k2 = next_bit(v2), k3 = next_bit(v3);
-                const double d0 = dp[k0], d1 = dp[k1], d2 = dp[k2], d3 = dp[k3];     // invalid slots read label 0: harmless
-                const uint32_t f0 = fp[k0], f1 = fp[k1], f2 = fp[k2], f3 = fp[k3];
-                const double c0 = __dadd_rn(d0, (double)flow_l1_biased(Fc, f0));
-                const double c1 = __dadd_rn(d1, (double)flow_l1_biased(Fc, f1));
-                const double c2 = __dadd_rn(d2, (double)flow_l1_biased(Fc, f2));
-                const double c3 = __dadd_rn(d3, (double)flow_l1_biased(Fc, f3));
-                bool t;
-                t = v0 && c0 < bestv; bestv = t ? c0 : bestv; bestk = t ? k0 : bestk;
-                t = v1 && c1 < bestv; bestv = t ? c1 : bestv; bestk = t ? k1 : bestk;
-                t = v2 && c2 < bestv; bestv = t ? c2 : bestv; bestk = t ? k2 : bestk;
-                t = v3 && c3 < bestv; bestv = t ? c3 : bestv; bestk = t ? k3 : bestk;
+            if (__ballot(cnt > BCD_LIST)) {
+                // some rows are denser: those lanes walk what is left of their 160-bit row behind the 8th list entry,
+                // four set bits per round (their LDS reads issued together); still increasing k, so strict '<' stands
+                const bool more = cnt > BCD_LIST;
+                const int k7 = kk[BCD_LIST - 1];
+                unsigned long long w0 = more ? ((unsigned long long)ra.x | ((unsigned long long)ra.y << 32)) : 0ull;
+                unsigned long long w1 = more ? ((unsigned long long)ra.z | ((unsigned long long)ra.w << 32)) : 0ull;
+                unsigned long long w2 = more ? (unsigned long long)rb.x : 0ull;
+                {
+                    const int b = k7 & 63;
+                    const unsigned long long keep = b == 63 ? 0ull : (~0ull << (b + 1));
+                    if (k7 < 64) w0 &= keep; else if (k7 < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
+                }
+                int base = 0;
+                auto next_bit = [&](bool &valid) {
+                    if (w0 == 0) { w0 = w1; w1 = w2; w2 = 0; base += 64; if (w0 == 0) { w0 = w1; w1 = 0; base += 64; } }
+                    valid = w0 != 0;
+                    int k = 0;
+                    if (valid) { k = base + __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
+                    return k;
+                };
+                while (w0 | w1 | w2) {
+                    bool v0, v1, v2, v3;
+                    const int k0 = next_bit(v0), k1 = next_bit(v1), k2 = next_bit(v2), k3 = next_bit(v3);
+                    const double d0 = dp[k0], d1 = dp[k1], d2 = dp[k2], d3 = dp[k3];     // invalid slots read label 0: harmless
+                    const uint32_t f0 = fp[k0], f1 = fp[k1], f2 = fp[k2], f3 = fp[k3];
+                    const double c0 = __dadd_rn(d0, (double)flow_l1_biased(Fc, f0));
+                    const double c1 = __dadd_rn(d1, (double)flow_l1_biased(Fc, f1));
+                    const double c2 = __dadd_rn(d2, (double)flow_l1_biased(Fc, f2));
+                    const double c3 = __dadd_rn(d3, (double)flow_l1_biased(Fc, f3));
+                    bool t;
+                    t = v0 && c0 < bestv; bestv = t ? c0 : bestv; bestk = t ? k0 : bestk;
+                    t = v1 && c1 < bestv; bestv = t ? c1 : bestv; bestk = t ? k1 : bestk;
+                    t = v2 && c2 < bestv; bestv = t ? c2 : bestv; bestk = t ? k2 : bestk;
+                    t = v3 && c3 < bestv; bestv = t ? c3 : bestv; bestk = t ? k3 : bestk;
+                }
             }
         }
         // permmincost / permminlabel (python bcd.py:152-157): first minimum of tpsi + dp[k] over the previous labels,
