@@ -27,7 +27,7 @@
 //
 // MFMA layout (v_mfma_f32_32x32x16_f16): A = candidates (rows), B = queries (columns): lane l holds
 // A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31]; D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5).
-// A workgroup is 4 waves x 64 queries (2 column groups) of one image-1 cell; candidates stream through LDS in
+// A workgroup is 8 waves x 64 queries (2 column groups) of one image-1 cell; candidates stream through LDS in
 // chunks of 96 rows (176-byte pitch: conflict-free ds_read_b128), double buffered by global_load_lds DMA.
 #include "dflow_common.h"
 
@@ -47,6 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KM_EVROWS 32            // event entries (tile, 16-bit row mask) per lane, group and candidate cell
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
 #define KM_LIST_WORDS (2 * KM_EVROWS * 64)       // one event list: [group][entry][lane] uint32
+#define KM_EVLIST 64             // candidates per lane and group the resolve kernel lists in LDS
 #define KM_KAPPA 0.001220703125f                 // k = 1.25 * 2^-10
 
 struct KmGeom {
@@ -219,20 +220,49 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 #pragma unroll
         for (int i = 0; i < 5; i++) a5[gq][i] = -INFINITY;
 
-    // A wave issues 3 (wave 0) or 2 DMA instructions per chunk.  Before the barrier that publishes chunk c+1 it waits
-    // until only the DMAs of chunks c+2 and c+3 (2 x its per-chunk count) may still be in flight; event stores issued
-    // in between only make that wait more conservative.  Chunks past the end are still "staged" (sentinel rows) so
-    // that the counts stay uniform.
-    auto wait_ring = [&]() {
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // A wave issues n_w (2 for wave 0, else 1) DMA instructions per chunk, and in pass 2 exactly 6 event stores (one per tile and
+    // column group, unconditionally: empty masks go to a scratch row).  Before the barrier that publishes chunk c+1 it
+    // waits until only the DMAs of chunks c+2 and c+3 and the stores of chunks c-1 and c may still be in flight
+    // (vmcnt counts all of them in issue order).  Chunks and tiles past the end of the cell are still staged/processed
+    // (sentinel rows) so that these counts are exact.
+    const int n_w = (17 - wave + KM_WAVES - 1) / KM_WAVES;           // DMA instructions of this wave per chunk (1 or 2)
+    auto wait_ring = [&](int pass) {
+        if (pass == 0) {
+            if (n_w == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            if (n_w == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
     };
+    // Epilogues.  Pass 1: the maximum of the 16 values of this lane's tile column enters the lane's top-5.
+    // Pass 2: 16-bit mask of the rows that qualify (bit r <-> accumulator register r) -> one event word.
+    auto epi1 = [&](const f32x16 &acc, int gq) { top5_insert_desc(a5[gq], max16(acc)); };
+    auto epi2 = [&](const f32x16 &acc, int gq, int tileidx) {
+        const float th = thr[gq];
+        // The compiler pads MFMA -> VALU hazards only for instructions it emits itself, so a plain max over the
+        // accumulator comes first and the asm below is made to depend on it.
+        uint32_t mask = max16(acc) >= th ? 0u : 0x10000u;   // bit 16 set <=> no row qualifies
+#pragma unroll
+        for (int r = 15; r >= 0; r--)   // mask = 2 mask + (acc[r] >= th): compare into vcc, add with carry-in
+            asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(acc[r]), "v"(th) : "vcc");
+        mask &= 0xFFFFu;
+        // always one store: real entries go to row cnt, empty masks to the scratch row KM_EVROWS-1 (a list that needs
+        // that row for data is reported as overflowed)
+        const int row = mask ? min(cnt[gq], KM_EVROWS - 1) : KM_EVROWS - 1;
+        myev[(size_t)(gq * KM_EVROWS + row) * 64] = ((uint32_t)tileidx << 16) | mask;
+        cnt[gq] += mask ? 1 : 0;
+    };
+    const f32x16 minus_inf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY,
+                              -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int pass = 0; pass < 2; pass++) {
         stage(0, 0); stage(1, 1); stage(2, 2);
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (n_w == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        // Software pipeline: the epilogue of the previous (tile, group) unit is issued behind the MFMAs of the current
+        // one, so the VALU work runs while the matrix pipe is busy.  The pipeline starts with a harmless unit (-inf).
+        f32x16 pend = minus_inf;
+        int pend_tile = 0;
         for (int chunk = 0; chunk < nchunks; chunk++) {
             const int buf = chunk & (KM_NBUF - 1);
             stage(chunk + 3, (chunk + 3) & (KM_NBUF - 1));                // that buffer was released by the previous barrier
@@ -240,40 +270,27 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
             if (wave_active) {
 #pragma unroll 1
                 for (int tile = 0; tile < KM_CHUNK / 32; tile++) {
-                    const int cbase = chunk * KM_CHUNK + tile * 32;
-                    if (cbase >= cnpts) break;
+                    const int tileidx = chunk * (KM_CHUNK / 32) + tile;
                     half8 af[5];
                     const char *arow = ab + (tile * 32 + col) * KM_PITCH + half * 16;
 #pragma unroll
                     for (int s = 0; s < 5; s++) af[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
+                    // unit (tile, group 0): MFMAs, then the pending epilogue of (previous tile, group 1)
+                    f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int gq = 0; gq < 2; gq++) {
-                        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int s = 0; s < 5; s++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[0][s], acc0, 0, 0, 0);
+                    if (pass == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile);
+                    // unit (tile, group 1): MFMAs, then the epilogue of (tile, group 0)
+                    f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[gq][s], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[4], bfrag[gq][4], acc, 0, 0, 0);
-                        if (pass == 0) {
-                            top5_insert_desc(a5[gq], max16(acc));
-                        } else {
-                            // 16-bit mask of the rows that qualify: bit r <-> accumulator register r
-                            const float th = thr[gq];
-                            // The compiler pads MFMA -> VALU hazards only for instructions it emits itself, so a plain
-                            // max over the accumulator comes first and the asm below is made to depend on it.
-                            uint32_t mask = max16(acc) >= th ? 0u : 0x10000u;   // bit 16 set <=> no row qualifies
-#pragma unroll
-                            for (int r = 15; r >= 0; r--)   // mask = 2 mask + (acc[r] >= th): compare into vcc, add with carry-in
-                                asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(acc[r]), "v"(th) : "vcc");
-                            mask &= 0xFFFFu;
-                            if (mask) {
-                                myev[(size_t)(gq * KM_EVROWS + min(cnt[gq], KM_EVROWS - 1)) * 64] = ((uint32_t)(cbase >> 5) << 16) | mask;
-                                cnt[gq]++;
-                            }
-                        }
-                    }
+                    for (int s = 0; s < 5; s++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[1][s], acc1, 0, 0, 0);
+                    if (pass == 0) epi1(acc0, 0); else epi2(acc0, 0, tileidx);
+                    pend = acc1; pend_tile = tileidx;
                 }
             }
-            wait_ring();
+            wait_ring(pass);
         }
+        if (wave_active) { if (pass == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile); }   // drain the pipeline
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the over-staged chunks before the buffers are reused
         __builtin_amdgcn_s_barrier();
         if (pass == 0) {
@@ -293,7 +310,7 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     }
     if (!wave_active) return;
 #pragma unroll
-    for (int gq = 0; gq < 2; gq++) p.ev_cnt[lid * 128 + gq * 64 + lane] = (uint8_t)(cnt[gq] > KM_EVROWS ? 255 : cnt[gq]);
+    for (int gq = 0; gq < 2; gq++) p.ev_cnt[lid * 128 + gq * 64 + lane] = (uint8_t)(cnt[gq] >= KM_EVROWS ? 255 : cnt[gq]);
 }
 
 // ------------------------------------------------------------------------------------------------ resolve
@@ -321,7 +338,7 @@ __device__ static inline void key_insert(unsigned long long (&k)[5], float (&c)[
 }
 
 // one wave per event list; lane = (query column lane&31, candidate half lane>>5), both groups in turn
-__global__ void __launch_bounds__(256, 3) knn_resolve_kernel(KmGeom a, KmResolve p, int nlists)
+__global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve p, int nlists)
 {
     const Geom g = a.g;
     const int lane = threadIdx.x & 63, half = lane >> 5;
@@ -351,6 +368,9 @@ __global__ void __launch_bounds__(256, 3) knn_resolve_kernel(KmGeom a, KmResolve
     }
     unsigned long long keys[2][5];
     float costs[2][5];
+    __shared__ uint16_t evl_all[4][KM_EVLIST][64];          // per wave: this lane's candidate indices, [slot][lane]
+    uint16_t (*evl)[64] = evl_all[threadIdx.x >> 6];
+    bool lane_ovf = false;
 #pragma unroll
     for (int gq = 0; gq < 2; gq++) {
         int qi = qwave * KM_QPW + gq * 32 + (lane & 31);
@@ -364,47 +384,60 @@ __global__ void __launch_bounds__(256, 3) knn_resolve_kernel(KmGeom a, KmResolve
         }
 #pragma unroll
         for (int i = 0; i < 5; i++) { keys[gq][i] = 0x7F800000FFFFFFFFull; costs[gq][i] = 0.0f; }   // (+inf, no index)
+        // ---- expand this lane's (tile, mask) entries into a list of candidate indices (increasing), in LDS
         const int n = gq == 0 ? c0 : c1;
         const uint32_t *ev = p.ev + (size_t)lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + lane;
-        for (int e = 0; e < n; e++) {
-            const uint32_t entry = ev[e * 64];
+        uint32_t ent[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) ent[e] = e < n ? ev[e * 64] : 0u;     // the first 8 entries are fetched together
+        int nev = 0;
+        auto expand = [&](uint32_t entry) {
             const int tbase = (int)(entry >> 16) * 32 + 4 * half;
             uint32_t mask = entry & 0xFFFFu;
             while (mask) {
                 const int r = __ffs(mask) - 1;
                 mask &= mask - 1;
-                const int idx = tbase + (r & 3) + 8 * (r >> 2);
-                const float4 *c4 = reinterpret_cast<const float4 *>(p.d2 + ((size_t)(cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * DFLOW_DESC);
-                // Canonical distance: sequential fmaf chain.  Its partial sums never decrease, so the chain stops as
-                // soon as it exceeds the lane's current 5th best: such a candidate cannot enter the top 5.
-                // The L1 cost (numpy pairwise order: 8 running sums, tree, 4 leftovers) rides along.
-                const float worst = __uint_as_float((unsigned)(keys[gq][4] >> 32));
-                float acc = 0.0f, rs[8], tail[4];
-                bool dead = false;
-                // three waits per event at most: 4 + 6 + 7 float4
-#pragma unroll
-                for (int seg = 0; seg < 3; seg++) {
-                    const int ka = seg == 0 ? 0 : (seg == 1 ? 4 : 10), kb = seg == 0 ? 4 : (seg == 1 ? 10 : 17);
-                    if (!dead) {
-#pragma unroll
-                        for (int k = ka; k < kb; k++) {
-                            const float4 v = c4[k];
-                            const float e0 = q[4 * k] - v.x, e1 = q[4 * k + 1] - v.y, e2 = q[4 * k + 2] - v.z, e3 = q[4 * k + 3] - v.w;
-                            acc = __fmaf_rn(e0, e0, acc); acc = __fmaf_rn(e1, e1, acc);
-                            acc = __fmaf_rn(e2, e2, acc); acc = __fmaf_rn(e3, e3, acc);
-                            const int j = (4 * k) & 7;
-                            if (k < 2) { rs[j] = fabsf(e0); rs[j + 1] = fabsf(e1); rs[j + 2] = fabsf(e2); rs[j + 3] = fabsf(e3); }
-                            else if (k < 16) { rs[j] = rs[j] + fabsf(e0); rs[j + 1] = rs[j + 1] + fabsf(e1); rs[j + 2] = rs[j + 2] + fabsf(e2); rs[j + 3] = rs[j + 3] + fabsf(e3); }
-                            else { tail[0] = fabsf(e0); tail[1] = fabsf(e1); tail[2] = fabsf(e2); tail[3] = fabsf(e3); }
-                        }
-                        dead = acc > worst;
-                    }
-                }
-                if (dead) continue;
-                float l1 = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
-                l1 = l1 + tail[0]; l1 = l1 + tail[1]; l1 = l1 + tail[2]; l1 = l1 + tail[3];
-                key_insert(keys[gq], costs[gq], ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)idx, l1);
+                if (nev < KM_EVLIST) evl[nev][lane] = (uint16_t)(tbase + (r & 3) + 8 * (r >> 2));
+                nev++;
             }
+        };
+#pragma unroll
+        for (int e = 0; e < 8; e++) expand(ent[e]);
+        for (int e = 8; e < n; e++) expand(ev[e * 64]);
+        lane_ovf |= nev > KM_EVLIST;
+        nev = min(nev, KM_EVLIST);
+        // ---- canonical distance (sequential fmaf chain) and L1 cost (numpy pairwise order) of every listed candidate
+        for (int r = 0; r < nev; r++) {
+            const int idx = evl[r][lane];
+            const float4 *c4 = reinterpret_cast<const float4 *>(p.d2 + ((size_t)(cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * DFLOW_DESC);
+            // The partial sums of the chain never decrease, so it stops once it exceeds the lane's current 5th best:
+            // such a candidate cannot enter the top 5 (it is then not inserted).  All 17 float4 of the row are fetched at once:
+            // the kernel is bound by L2 latency, not bandwidth.
+            const float worst = __uint_as_float((unsigned)(keys[gq][4] >> 32));
+            float acc = 0.0f, rs[8], tail[4];
+            bool dead = false;
+#pragma unroll
+            for (int seg = 0; seg < 1; seg++) {
+                const int ka = 0, kb = 17;
+                if (!dead) {
+#pragma unroll
+                    for (int k = ka; k < kb; k++) {
+                        const float4 v = c4[k];
+                        const float e0 = q[4 * k] - v.x, e1 = q[4 * k + 1] - v.y, e2 = q[4 * k + 2] - v.z, e3 = q[4 * k + 3] - v.w;
+                        acc = __fmaf_rn(e0, e0, acc); acc = __fmaf_rn(e1, e1, acc);
+                        acc = __fmaf_rn(e2, e2, acc); acc = __fmaf_rn(e3, e3, acc);
+                        const int j = (4 * k) & 7;
+                        if (k < 2) { rs[j] = fabsf(e0); rs[j + 1] = fabsf(e1); rs[j + 2] = fabsf(e2); rs[j + 3] = fabsf(e3); }
+                        else if (k < 16) { rs[j] = rs[j] + fabsf(e0); rs[j + 1] = rs[j + 1] + fabsf(e1); rs[j + 2] = rs[j + 2] + fabsf(e2); rs[j + 3] = rs[j + 3] + fabsf(e3); }
+                        else { tail[0] = fabsf(e0); tail[1] = fabsf(e1); tail[2] = fabsf(e2); tail[3] = fabsf(e3); }
+                    }
+                    dead = acc > worst;
+                }
+            }
+            if (dead) continue;
+            float l1 = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+            l1 = l1 + tail[0]; l1 = l1 + tail[1]; l1 = l1 + tail[2]; l1 = l1 + tail[3];
+            key_insert(keys[gq], costs[gq], ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)idx, l1);
         }
         // the other half-lane screened the other 16 rows of every tile: merge
         unsigned long long ok[5]; float oc[5];
@@ -412,6 +445,13 @@ __global__ void __launch_bounds__(256, 3) knn_resolve_kernel(KmGeom a, KmResolve
         for (int i = 0; i < 5; i++) { ok[i] = __shfl_xor(keys[gq][i], 32); oc[i] = __shfl_xor(costs[gq][i], 32); }
 #pragma unroll
         for (int i = 0; i < 5; i++) key_insert(keys[gq], costs[gq], ok[i], oc[i]);
+    }
+    if (__ballot(lane_ovf)) {                        // more candidates than list slots: exact redo by knn_fix_kernel
+        if (lane == 0) {
+            int pos = atomicAdd(p.ovf_count, 1);
+            if (pos < p.ovf_cap) p.ovf_list[pos] = make_int4(qcell, qwave * KM_QPW, ci, cj);
+        }
+        return;
     }
     // ---- emit (daisy i flann.py:174-180): lane l < 32 writes group 0 / column l, lane l >= 32 group 1 / column l-32
     const int qi = qwave * KM_QPW + lane;
