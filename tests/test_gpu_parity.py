@@ -182,3 +182,98 @@ def test_full_size_sintel_properties_and_sampled_parity(torch_, oracle, synth):
     flow = df.vratiKonacniFlow().cpu().numpy()
     epe = np.sqrt(((flow - gt) ** 2).sum(-1))
     assert np.median(epe) < 5.0
+
+
+@pytest.mark.parametrize("geom", [(375, 1241, 25, 73), (375, 1242, 25, 54)])
+def test_kitti_geometries_sampled(torch_, oracle, synth, geom):
+    """BASELINE configs 1 and 5 geometries (daisy i flann.py:34-43, discrete_flow.py:22-31): invariants, sampled exact
+    kNN searches and one full BCD sweep against the oracle."""
+    H, W, ch, cw = geom
+    O = oracle
+    img1, img2, _ = synth.make_pair(H, W, seed=H + W)
+    df = make(H, W, ch, cw, seed=3)
+    p = oracle_params(O, df)
+    df.load_pair(img1, img2)
+    d1, d2 = df.descrs1.cpu().numpy(), df.descrs2.cpu().numpy()
+    df.generisi()
+    st = df.host_state()
+    pr, lc, npr, bl = st["proposals"], st["lcosts"], st["nprop"], st["bestlabels"]
+    ncx, ncy = W // cw, H // ch
+    cy = np.minimum(np.arange(H) // ch, ncy - 1); cx = np.minimum(np.arange(W) // cw, ncx - 1)
+    wy = np.minimum(cy + 2, ncy - 1) - np.maximum(cy - 2, 0) + 1
+    wx = np.minimum(cx + 2, ncx - 1) - np.maximum(cx - 2, 0) + 1
+    assert np.array_equal(npr, 5 * wy[:, None] * wx[None, :])
+    valid = np.arange(p.maxnprop)[None, None, :] < npr[..., None]
+    assert np.array_equal(bl, np.argmin(np.where(valid, lc, np.inf), axis=-1))
+    rng = np.random.default_rng(7)
+    for _ in range(12):
+        y, x = int(rng.integers(H)), int(rng.integers(W))
+        slot = 0
+        for ci in range(max(0, cx[x] - 2), min(ncx - 1, cx[x] + 2) + 1):
+            for cj in range(max(0, cy[y] - 2), min(ncy - 1, cy[y] + 2) + 1):
+                idx, _ = O.knn_cell(p, d1[y, x], d2, ci, cj)
+                cwid = (W if ci == ncx - 1 else (ci + 1) * cw) - ci * cw
+                want = np.stack([cj * ch + idx // cwid - y, ci * cw + idx % cwid - x], -1)
+                assert np.array_equal(pr[y, x, slot:slot + 5], want), (y, x, ci, cj)
+                slot += 5
+    df.nasumicni()
+    O.neighbour_proposals(p, d1, d2, pr, lc, npr, bl)
+    st = df.host_state()
+    assert np.array_equal(st["nprop"], npr) and np.array_equal(st["proposals"], pr) and np.array_equal(st["lcosts"], lc)
+    df.ceoBCD(1)
+    O.bcd_sweep(p, pr, lc, npr, bl)
+    assert np.array_equal(df.bestlabels.cpu().numpy(), bl)
+
+
+def test_knn_mfma_path_equals_exact_kernel(torch_, synth, monkeypatch):
+    """The MFMA-screened search and the brute-force VALU kernel (DFLOW_KNN=exact) give identical outputs, also where the
+    screen has to hand work back: negative descriptor values force the exact fix-up pass."""
+    H, W, ch, cw = 96, 128, 12, 16
+    img1, img2, _ = synth.make_pair(H, W, seed=5, amp_x=8, amp_y=6)
+    df = make(H, W, ch, cw)
+    df.load_pair(img1, img2)
+
+    def run(mode, d1, d2):
+        if mode:
+            monkeypatch.setenv("DFLOW_KNN", mode)
+        else:
+            monkeypatch.delenv("DFLOW_KNN", raising=False)
+        df.set_descriptors(d1, d2)
+        df.generisi()
+        return df.host_state()
+
+    d1, d2 = df.descrs1.clone(), df.descrs2.clone()
+    a, b = run(None, d1, d2), run("exact", d1, d2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # negative values (never produced by DAISY): outside the premises of the f16 error bound -> whole pass via fix-up
+    d1n = d1 - 0.01
+    a, b = run(None, d1n, d2), run("exact", d1n, d2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
+    """The two drop-in CLIs on a synthetic pair: file names, dtypes and contents as the reference writes them."""
+    import runpy, sys, os
+    from conftest import ROOT, PKG
+    O = oracle
+    H, W, ch, cw = 48, 64, 8, 8
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(sys, "argv", ["daisy i flann.py", "6", "0", "1", "--synthetic", "%dx%d" % (H, W), "--cell", "%dx%d" % (ch, cw), "--seed", "11"])
+    runpy.run_path(os.path.join(ROOT, PKG, "daisy i flann.py"), run_name="__main__")
+    monkeypatch.setattr(sys, "argv", ["python bcd.py", "6", "0", "2", "--cell", "%dx%d" % (ch, cw)])
+    runpy.run_path(os.path.join(ROOT, PKG, "python bcd.py"), run_name="__main__")
+    img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(6, 0))
+    ref = O.full_pass(O.make_params(H, W, ch, cw, seed=11), img1, img2, 2)
+    prop = np.load("Daisy output slike 106 backward=0 proposals_nakon_gausa.npy")
+    assert prop.dtype == np.int64 and prop.shape == (H, W, 150, 2) and np.array_equal(prop, ref["proposals"])
+    lc = np.load("Daisy output slike 106 backward=0 lcosts_nakon_gausa.npy")
+    assert lc.dtype == np.float64 and np.array_equal(lc, ref["lcosts"])
+    assert np.array_equal(np.load("Daisy output slike 106 backward=0 nprop.npy"), ref["nprop"])
+    for w in range(3):
+        f = np.load("Gotova flow slika 106 backward=0 posle %02d BCD.npy" % w)
+        assert f.dtype == np.float64 and np.array_equal(f, ref["flows"][w])
+        flo = pkg("flowio").read_flo("Gotova flow slika 106 backward=0 posle %02d BCD.flo" % w)
+        assert np.array_equal(flo, f[..., ::-1].astype(np.float32))
+    assert np.array_equal(np.load("Bestlabels fajl slike 106 backward=0 posle 02 BCD.npy"), ref["bestlabels"])
