@@ -19,8 +19,10 @@
 
 #define BCD_THREADS 192
 #define BCD_MASK_WORDS 5                 // 160 bits per label row
-#define BCD_ROW_WORDS 8                  // one row record: 5 mask words, 2 words = first 8 set bits as bytes (0xFF = none), 1 word = popcount
-#define BCD_LIST 8
+#define BCD_ROW_WORDS 8                  // LDS staging pitch of one row (5 mask words + scratch)
+#define BCD_REC_WORDS 6                  // row record the chain kernel reads every step: 4 words = the first 16 set bits as
+                                         // bytes (0xFF = none), 1 word = popcount, 1 pad; the 5 mask words live in a second array
+#define BCD_LIST 16
 #define BCD_LDS_LABELS 256
 #define BCD_TB_STEPS 128                 // traceback chunk (steps) staged in LDS
 
@@ -36,7 +38,8 @@ __device__ static inline void chain_geom(int phase, int chain, int H, int W, int
 // ------------------------------------------------------------------------------------------------ masks
 // grid: one wave per (pixel, dir); dir 0 = the pixel's column chain, dir 1 = its row chain.
 __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, int tpsi, const uint32_t *__restrict__ proposals,
-                                                        const int32_t *__restrict__ nprop, uint32_t *__restrict__ masks)
+                                                        const int32_t *__restrict__ nprop, uint32_t *__restrict__ masks,
+                                                        uint32_t *__restrict__ recs)
 {
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -73,31 +76,35 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
         w = lane == 4 ? (uint32_t)m2 : w;
         if (lane < BCD_MASK_WORDS) st[tl * BCD_ROW_WORDS + lane] = w;
     }
-    // second half, lanes = rows: the first 8 set bits of every row as a byte list (what the chain kernel reads in the
+    // second half, lanes = rows: the first 16 set bits of every row as a byte list (what the chain kernel reads in the
     // common case) and the row's popcount (same wave wrote the masks: LDS operations of a wave complete in order)
+    const size_t rowbase = ((size_t)pix * 2 + dir) * (size_t)LP;
     for (int tl = lane; tl < tn; tl += 64) {
         uint32_t m[BCD_MASK_WORDS];
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < BCD_MASK_WORDS; j++) { m[j] = st[tl * BCD_ROW_WORDS + j]; cnt += __popc(m[j]); }
-        uint32_t l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu;
+        uint32_t l[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         int n = 0;
 #pragma unroll
         for (int j = 0; j < BCD_MASK_WORDS; j++) {
             uint32_t w = m[j];
             while (w && n < BCD_LIST) {
                 const uint32_t k = 32 * j + __ffs(w) - 1; w &= w - 1;
-                if (n < 4) l0 = (l0 & ~(0xFFu << (8 * n))) | (k << (8 * n));
-                else l1 = (l1 & ~(0xFFu << (8 * (n - 4)))) | (k << (8 * (n - 4)));
+                const uint32_t sh = 8 * (n & 3), clr = ~(0xFFu << sh), val = k << sh;
+                if (n < 4) l[0] = (l[0] & clr) | val; else if (n < 8) l[1] = (l[1] & clr) | val;
+                else if (n < 12) l[2] = (l[2] & clr) | val; else l[3] = (l[3] & clr) | val;
                 n++;
             }
         }
-        st[tl * BCD_ROW_WORDS + 5] = l0; st[tl * BCD_ROW_WORDS + 6] = l1; st[tl * BCD_ROW_WORDS + 7] = (uint32_t)cnt;
+        uint32_t *rec = recs + (rowbase + tl) * BCD_REC_WORDS;
+        *reinterpret_cast<uint2 *>(rec) = make_uint2(l[0], l[1]);
+        *reinterpret_cast<uint2 *>(rec + 2) = make_uint2(l[2], l[3]);
+        *reinterpret_cast<uint2 *>(rec + 4) = make_uint2((uint32_t)cnt, 0u);
     }
-    // one coalesced copy of the tn row records
-    uint4 *out = reinterpret_cast<uint4 *>(masks + ((size_t)pix * 2 + dir) * (size_t)LP * BCD_ROW_WORDS);
-    const uint4 *src = reinterpret_cast<const uint4 *>(st);
-    for (int j = lane; j < tn * (BCD_ROW_WORDS / 4); j += 64) out[j] = src[j];
+    // the 160-bit rows themselves (read by the chain kernel only for rows with more than 16 set bits)
+    uint32_t *out = masks + rowbase * BCD_MASK_WORDS;
+    for (int j = lane; j < tn * BCD_MASK_WORDS; j += 64) out[j] = st[(j / BCD_MASK_WORDS) * BCD_ROW_WORDS + j % BCD_MASK_WORDS];
 }
 
 // ------------------------------------------------------------------------------------------------ chains
@@ -108,7 +115,7 @@ struct BcdArgs {
     const float *lcosts;
     const int32_t *nprop;
     int32_t *bestlabels;
-    const uint32_t *masks;
+    const uint32_t *masks, *recs;
     uint8_t *back;
 };
 
@@ -233,14 +240,15 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     // Per-step inputs of this thread, prefetched three steps ahead.  All loads are unconditional (rows are LP wide;
     // mask rows of unused labels hold garbage that is masked at use), so nothing in a step waits for a load issued
     // in the same step.
-    struct StepIn { uint32_t F; float lc; uint4 ra, rb; };   // ra = mask words 0..3, rb = {mask word 4, list 0..3, list 4..7, popcount}
+    struct StepIn { uint32_t F; float lc; uint4 rl; uint32_t cnt; };   // rl = byte list of the first 16 compatible labels
     auto fetch = [&](int i) {
         StepIn r;
         const int pix = pix0 + min(i, len - 1) * pstep;
         r.F = flow_bias(a.proposals[(size_t)pix * LP + tl]);
         r.lc = a.lcosts[(size_t)pix * LP + tl];
-        const uint4 *row = reinterpret_cast<const uint4 *>(a.masks + (((size_t)pix * 2 + dir) * LP + tl) * BCD_ROW_WORDS);
-        r.ra = row[0]; r.rb = row[1];
+        const uint32_t *rec = a.recs + (((size_t)pix * 2 + dir) * LP + tl) * BCD_REC_WORDS;
+        const uint2 r01 = *reinterpret_cast<const uint2 *>(rec), r23 = *reinterpret_cast<const uint2 *>(rec + 2);
+        r.rl = make_uint4(r01.x, r01.y, r23.x, r23.y); r.cnt = rec[4];
         return r;
     };
     const StepIn S0 = fetch(0);
@@ -275,7 +283,8 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         const uint32_t Fc = in.F;
         const float lc = in.lc;
         const bool act = owner && tl < tn;
-        const uint4 ra = in.ra, rb = in.rb;
+        const uint4 rl = in.rl; const uint32_t rcnt = in.cnt;
+        const size_t rowidx = ((size_t)(pix0 + i * pstep) * 2 + dir) * LP + tl;
         in = fetch(i + 3);
         const double *dp = dpbuf + (cur ^ 1) * BCD_LDS_LABELS;
         const uint32_t *fp = fpbuf + (cur ^ 1) * BCD_LDS_LABELS;
@@ -284,35 +293,40 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         // increasing k (strict '<' keeps the first minimum); the LDS reads of the next candidate are issued before the
         // current one is evaluated
         double bestv = 1e300; int bestk = 0x7fffffff;
-        const int cnt = act ? (int)rb.w : 0;
+        const int cnt = act ? (int)rcnt : 0;
         {
-            // The first 8 compatible predecessors of every row come as a byte list in increasing k (0xFF = none, which
-            // reads the +inf tail of dp); all 16 LDS reads are issued together.
-            const uint32_t l0 = act ? rb.y : 0xFFFFFFFFu, l1 = act ? rb.z : 0xFFFFFFFFu;
-            int kk[BCD_LIST]; double dd[BCD_LIST]; uint32_t ff[BCD_LIST];
+            // The first 16 compatible predecessors of every row come as a byte list in increasing k (0xFF = none, which
+            // reads the +inf tail of dp); the LDS reads of 8 candidates are issued together.
+            auto list8 = [&](uint32_t la, uint32_t lb) {
+                int kk[8]; double dd[8]; uint32_t ff[8];
 #pragma unroll
-            for (int j = 0; j < BCD_LIST; j++) {
-                kk[j] = (int)(((j < 4 ? l0 : l1) >> (8 * (j & 3))) & 0xFFu);
-                dd[j] = dp[kk[j]]; ff[j] = fp[kk[j]];
-            }
+                for (int j = 0; j < 8; j++) {
+                    kk[j] = (int)(((j < 4 ? la : lb) >> (8 * (j & 3))) & 0xFFu);
+                    dd[j] = dp[kk[j]]; ff[j] = fp[kk[j]];
+                }
 #pragma unroll
-            for (int j = 0; j < BCD_LIST; j++) {
-                const double c = __dadd_rn(dd[j], (double)flow_l1_biased(Fc, ff[j]));
-                const bool t = c < bestv;               // +inf + psi = +inf never wins
-                bestv = t ? c : bestv; bestk = t ? kk[j] : bestk;
-            }
+                for (int j = 0; j < 8; j++) {
+                    const double c = __dadd_rn(dd[j], (double)flow_l1_biased(Fc, ff[j]));
+                    const bool t = c < bestv;               // +inf + psi = +inf never wins
+                    bestv = t ? c : bestv; bestk = t ? kk[j] : bestk;
+                }
+            };
+            list8(act ? rl.x : 0xFFFFFFFFu, act ? rl.y : 0xFFFFFFFFu);
+            if (__ballot(cnt > 8)) list8(act ? rl.z : 0xFFFFFFFFu, act ? rl.w : 0xFFFFFFFFu);
             if (__ballot(cnt > BCD_LIST)) {
-                // some rows are denser: those lanes walk what is left of their 160-bit row behind the 8th list entry,
-                // four set bits per round (their LDS reads issued together); still increasing k, so strict '<' stands
+                // some rows are denser still: those lanes fetch their 160-bit row and walk what is left behind the 16th
+                // list entry, four set bits per round; still increasing k, so strict '<' stands
                 const bool more = cnt > BCD_LIST;
-                const int k7 = kk[BCD_LIST - 1];
-                unsigned long long w0 = more ? ((unsigned long long)ra.x | ((unsigned long long)ra.y << 32)) : 0ull;
-                unsigned long long w1 = more ? ((unsigned long long)ra.z | ((unsigned long long)ra.w << 32)) : 0ull;
-                unsigned long long w2 = more ? (unsigned long long)rb.x : 0ull;
-                {
-                    const int b = k7 & 63;
+                const int k15 = (int)(rl.w >> 24);
+                const uint32_t *mrow = a.masks + rowidx * BCD_MASK_WORDS;
+                unsigned long long w0 = 0, w1 = 0, w2 = 0;
+                if (more) {
+                    w0 = (unsigned long long)mrow[0] | ((unsigned long long)mrow[1] << 32);
+                    w1 = (unsigned long long)mrow[2] | ((unsigned long long)mrow[3] << 32);
+                    w2 = (unsigned long long)mrow[4];
+                    const int b = k15 & 63;
                     const unsigned long long keep = b == 63 ? 0ull : (~0ull << (b + 1));
-                    if (k7 < 64) w0 &= keep; else if (k7 < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
+                    if (k15 < 64) w0 &= keep; else if (k15 < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
                 }
                 int base = 0;
                 auto next_bit = [&](bool &valid) {
@@ -339,8 +353,6 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
                 }
             }
         }
-        // permmincost / permminlabel (python bcd.py:152-157): first minimum of tpsi + dp[k] over the previous labels,
-        // merged from the per-wave minima the previous step left in LDS (waves are in label order)
         // waves are in label order and every partial index is the first one inside its wave
         Cand perm;
         {
@@ -440,17 +452,23 @@ static size_t back_bytes(const dflow_params *p)
 
 static size_t mask_bytes(const dflow_params *p)
 {
-    return (size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_ROW_WORDS * sizeof(uint32_t);
+    return (size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_MASK_WORDS * sizeof(uint32_t);
 }
 
-size_t bcd_ws_bytes(const dflow_params *p) { return back_bytes(p) + mask_bytes(p); }
+static size_t rec_bytes(const dflow_params *p)
+{
+    return (size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_REC_WORDS * sizeof(uint32_t);
+}
+
+size_t bcd_ws_bytes(const dflow_params *p) { return back_bytes(p) + mask_bytes(p) + rec_bytes(p); }
 
 int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, void *ws, hipStream_t s)
 {
     uint32_t *masks = (uint32_t *)((char *)ws + back_bytes(p));
+    uint32_t *recs = (uint32_t *)((char *)ws + back_bytes(p) + mask_bytes(p));
     long long items = 2LL * p->pich * p->picw;
     hipLaunchKernelGGL(bcd_masks_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p->pich, p->picw, p->label_pitch,
-                       p->tpsi, proposals, nprop, masks);
+                       p->tpsi, proposals, nprop, masks, recs);
     return dflow_check_launch("bcd_masks_kernel");
 }
 
@@ -464,6 +482,7 @@ int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const flo
     a.H = p->pich; a.W = p->picw; a.LP = p->label_pitch; a.tpsi = p->tpsi; a.phase = phase; a.lamda = p->lamda;
     a.proposals = proposals; a.lcosts = lcosts; a.nprop = nprop; a.bestlabels = bestlabels;
     a.back = (uint8_t *)ws; a.masks = (const uint32_t *)((char *)ws + back_bytes(p));
+    a.recs = (const uint32_t *)((char *)ws + back_bytes(p) + mask_bytes(p));
     size_t shmem = 2 * 256 * (sizeof(double) + sizeof(uint32_t)) + 2 * 4 * (sizeof(double) + sizeof(int)) + 16 +
                    (size_t)BCD_TB_STEPS * p->label_pitch + (size_t)len * (sizeof(uint32_t) + sizeof(int));
     hipLaunchKernelGGL(bcd_chain_kernel, dim3(nchains), dim3(BCD_THREADS), shmem, s, a);

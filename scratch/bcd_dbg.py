@@ -15,4 +15,4 @@ for ph in (0,1):
     steps = d[0,7]-1
     print('phase',ph,'steps',steps)
     for w in range(3):
-        print(' wave',w,'cycles/step: fetch+setup %.0f bitloop %.0f perm+final %.0f wavemin %.0f barrier %.0f | trips/step %.1f max %d'%(d[w,0]/steps,d[w,1]/steps,d[w,2]/steps,d[w,3]/steps,d[w,4]/steps,d[w,6]/steps,d[w,5]))
+        print(' wave',w,'cycles/step: setup %.0f list %.0f residual %.0f perm+final %.0f wavemin %.0f barrier %.0f'%(d[w,0]/steps,d[w,1]/steps,d[w,5]/steps,d[w,2]/steps,d[w,3]/steps,d[w,4]/steps))
