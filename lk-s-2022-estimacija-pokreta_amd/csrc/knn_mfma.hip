@@ -472,22 +472,37 @@ __global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve
 
 // ------------------------------------------------------------------------------------------------ finalize
 // nprop = 5 x window cells (daisy i flann.py:189), WTA label = first minimum of the costs with strict '<'
-// from 1000.0 (:93,181-184), fills beyond nprop (:89-90)
-__global__ void knn_finalize_kernel(Geom g, int LP, uint32_t *__restrict__ proposals, float *__restrict__ lcosts,
-                                    int32_t *__restrict__ nprop, int32_t *__restrict__ bestlabels)
+// from 1000.0 (:93,181-184), fills beyond nprop (:89-90).  16 lanes per pixel: coalesced reads of the cost row,
+// (cost, slot) lexicographic minimum over the 16 lanes with DPP row shifts, coalesced fills.
+__global__ void __launch_bounds__(256) knn_finalize_kernel(Geom g, int LP, uint32_t *__restrict__ proposals, float *__restrict__ lcosts,
+                                                           int32_t *__restrict__ nprop, int32_t *__restrict__ bestlabels)
 {
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= g.H * g.W) return;
-    const int cy = g.celly(pix / g.W), cx = g.cellx(pix % g.W);
+    const int sub = threadIdx.x & 15;
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool ok = pix < g.H * g.W;
+    const int px = ok ? pix : 0;
+    const int cy = g.celly(px / g.W), cx = g.cellx(px % g.W);
     const int wy = min(g.ncy - 1, cy + g.win) - max(0, cy - g.win) + 1;
     const int wx = min(g.ncx - 1, cx + g.win) - max(0, cx - g.win) + 1;
     const int n = 5 * wy * wx;
-    const float *lc = lcosts + (size_t)pix * LP;
-    float mind = 1000.0f; int best = 0;
-    for (int l = 0; l < n; l++) { float c = lc[l]; if (c < mind) { mind = c; best = l; } }
-    nprop[pix] = n;
-    bestlabels[pix] = best;
-    for (int l = n; l < LP; l++) { proposals[(size_t)pix * LP + l] = DFLOW_FILL_PROPOSAL; lcosts[(size_t)pix * LP + l] = DFLOW_FILL_COST; }
+    const float *lc = lcosts + (size_t)px * LP;
+    float mind = 1000.0f; int best = 0x7fffffff;
+    for (int l = sub; l < n; l += 16) { const float c = lc[l]; if (c < mind) { mind = c; best = l; } }
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1) {       // row_shl 1,2,4,8: lane 0 of every 16-lane row ends with the row minimum
+        const int ctrl = 0x100 + sh;
+        float om; int ob;
+        if (sh == 1) { om = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, mind), __builtin_bit_cast(int, mind), 0x101, 0xF, 0xF, false)); ob = __builtin_amdgcn_update_dpp(best, best, 0x101, 0xF, 0xF, false); }
+        else if (sh == 2) { om = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, mind), __builtin_bit_cast(int, mind), 0x102, 0xF, 0xF, false)); ob = __builtin_amdgcn_update_dpp(best, best, 0x102, 0xF, 0xF, false); }
+        else if (sh == 4) { om = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, mind), __builtin_bit_cast(int, mind), 0x104, 0xF, 0xF, false)); ob = __builtin_amdgcn_update_dpp(best, best, 0x104, 0xF, 0xF, false); }
+        else { om = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, mind), __builtin_bit_cast(int, mind), 0x108, 0xF, 0xF, false)); ob = __builtin_amdgcn_update_dpp(best, best, 0x108, 0xF, 0xF, false); }
+        (void)ctrl;
+        if (om < mind || (om == mind && ob < best)) { mind = om; best = ob; }
+    }
+    if (ok) {
+        if (sub == 0) { nprop[pix] = n; bestlabels[pix] = best == 0x7fffffff ? 0 : best; }
+        for (int l = n + sub; l < LP; l += 16) { proposals[(size_t)pix * LP + l] = DFLOW_FILL_PROPOSAL; lcosts[(size_t)pix * LP + l] = DFLOW_FILL_COST; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -563,6 +578,6 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     if (rc) return rc;
     rc = launch_knn_fix(p, d1, d2, proposals, lcosts, ctr, ovf, KM_OVF_CAP, ctr + 1, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(knn_finalize_kernel, dim3(nb), dim3(256), 0, s, g, a.LP, proposals, lcosts, nprop, bestlabels);
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)((N * 16 + 255) / 256)), dim3(256), 0, s, g, a.LP, proposals, lcosts, nprop, bestlabels);
     return dflow_check_launch("knn_finalize_kernel");
 }
