@@ -19,7 +19,6 @@
 
 #define BCD_THREADS 192
 #define BCD_MASK_WORDS 5                 // 160 bits per label row
-#define BCD_ROW_WORDS 8                  // LDS staging pitch of one row (5 mask words + scratch)
 #define BCD_REC_WORDS 6                  // row record the chain kernel reads every step: 4 words = the first 16 set bits as
                                          // bytes (0xFF = none), 1 word = popcount, 1 pad; the 5 mask words live in a second array
 #define BCD_LIST 16
@@ -53,8 +52,6 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
     if (py < 0 || py >= H || px < 0 || px >= W) return;       // chain start: no transition into this pixel
     const int ppix = py * W + px;
     const int tn = nprop[pix], pn = nprop[ppix];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[4][DFLOW_MAX_LABELS * BCD_ROW_WORDS];
-    uint32_t *st = stage[threadIdx.x >> 6];
     uint32_t fp[3], fcv[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -62,49 +59,55 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
         fp[j] = k < pn ? flow_bias(proposals[(size_t)ppix * LP + k]) : 0u;   // 0: far from every biased flow
         fcv[j] = k < tn ? flow_bias(proposals[(size_t)pix * LP + k]) : 0u;
     }
-    for (int tl = 0; tl < tn; tl++) {
-        // label tl of this pixel, broadcast from the lane that holds it (wave-uniform)
-        const uint32_t fsel = tl < 64 ? fcv[0] : (tl < 128 ? fcv[1] : fcv[2]);
-        const uint32_t fc = __builtin_amdgcn_readlane(fsel, tl & 63);
-        const unsigned long long m0 = __ballot(flow_l1_biased(fc, fp[0]) < (uint32_t)tpsi);
-        const unsigned long long m1 = __ballot(flow_l1_biased(fc, fp[1]) < (uint32_t)tpsi);
-        const unsigned long long m2 = __ballot(flow_l1_biased(fc, fp[2]) < (uint32_t)tpsi);
-        uint32_t w = (uint32_t)m0;
-        w = lane == 1 ? (uint32_t)(m0 >> 32) : w;
-        w = lane == 2 ? (uint32_t)m1 : w;
-        w = lane == 3 ? (uint32_t)(m1 >> 32) : w;
-        w = lane == 4 ? (uint32_t)m2 : w;
-        if (lane < BCD_MASK_WORDS) st[tl * BCD_ROW_WORDS + lane] = w;
-    }
-    // second half, lanes = rows: the first 16 set bits of every row as a byte list (what the chain kernel reads in the
-    // common case) and the row's popcount (same wave wrote the masks: LDS operations of a wave complete in order)
     const size_t rowbase = ((size_t)pix * 2 + dir) * (size_t)LP;
-    for (int tl = lane; tl < tn; tl += 64) {
-        uint32_t m[BCD_MASK_WORDS];
-        int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < BCD_MASK_WORDS; j++) { m[j] = st[tl * BCD_ROW_WORDS + j]; cnt += __popc(m[j]); }
-        uint32_t l[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        int n = 0;
-#pragma unroll
-        for (int j = 0; j < BCD_MASK_WORDS; j++) {
-            uint32_t w = m[j];
-            while (w && n < BCD_LIST) {
-                const uint32_t k = 32 * j + __ffs(w) - 1; w &= w - 1;
-                const uint32_t sh = 8 * (n & 3), clr = ~(0xFFu << sh), val = k << sh;
-                if (n < 4) l[0] = (l[0] & clr) | val; else if (n < 8) l[1] = (l[1] & clr) | val;
-                else if (n < 12) l[2] = (l[2] & clr) | val; else l[3] = (l[3] & clr) | val;
-                n++;
-            }
+    for (int grp = 0; grp < 3; grp++) {
+        const int nrows = min(64, tn - 64 * grp);          // rows 64 grp .. 64 grp + nrows - 1 (wave-uniform)
+        if (nrows <= 0) break;
+        // lanes = predecessor labels: one v_sad_u16 + compare per 64 pairs, the ballot is a mask word; the 5
+        // words of row r are deposited in lane r, so that afterwards lane = row
+        uint32_t m[BCD_MASK_WORDS] = {0u, 0u, 0u, 0u, 0u};
+        for (int r = 0; r < nrows; r++) {
+            const uint32_t fc = __builtin_amdgcn_readlane(fcv[grp], r);      // label 64 grp + r of this pixel
+            const unsigned long long m0 = __ballot(flow_l1_biased(fc, fp[0]) < (uint32_t)tpsi);
+            const unsigned long long m1 = __ballot(flow_l1_biased(fc, fp[1]) < (uint32_t)tpsi);
+            const unsigned long long m2 = __ballot(flow_l1_biased(fc, fp[2]) < (uint32_t)tpsi);
+            const bool mine = lane == r;                       // deposit the 5 words of row r in lane r
+            m[0] = mine ? (uint32_t)m0 : m[0];
+            m[1] = mine ? (uint32_t)(m0 >> 32) : m[1];
+            m[2] = mine ? (uint32_t)m1 : m[2];
+            m[3] = mine ? (uint32_t)(m1 >> 32) : m[3];
+            m[4] = mine ? (uint32_t)m2 : m[4];
         }
-        uint32_t *rec = recs + (rowbase + tl) * BCD_REC_WORDS;
-        *reinterpret_cast<uint2 *>(rec) = make_uint2(l[0], l[1]);
-        *reinterpret_cast<uint2 *>(rec + 2) = make_uint2(l[2], l[3]);
-        *reinterpret_cast<uint2 *>(rec + 4) = make_uint2((uint32_t)cnt, 0u);
+        if (lane < nrows) {
+            // lane = row: the first 16 set bits as a byte list (what the chain kernel reads every step) and the popcount
+            const int tl = 64 * grp + lane;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < BCD_MASK_WORDS; j++) cnt += __popc(m[j]);
+            uint32_t l[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            int n = 0;
+#pragma unroll
+            for (int j = 0; j < BCD_MASK_WORDS; j++) {
+                uint32_t w = m[j];
+                while (w && n < BCD_LIST) {
+                    const uint32_t k = 32 * j + __ffs(w) - 1; w &= w - 1;
+                    const uint32_t sh = 8 * (n & 3), clr = ~(0xFFu << sh), val = k << sh;
+                    if (n < 4) l[0] = (l[0] & clr) | val; else if (n < 8) l[1] = (l[1] & clr) | val;
+                    else if (n < 12) l[2] = (l[2] & clr) | val; else l[3] = (l[3] & clr) | val;
+                    n++;
+                }
+            }
+            uint32_t *rec = recs + (rowbase + tl) * BCD_REC_WORDS;
+            *reinterpret_cast<uint2 *>(rec) = make_uint2(l[0], l[1]);
+            *reinterpret_cast<uint2 *>(rec + 2) = make_uint2(l[2], l[3]);
+            *reinterpret_cast<uint2 *>(rec + 4) = make_uint2((uint32_t)cnt, 0u);
+            // the 160-bit row itself (read by the chain kernel only for rows with more than 16 set bits)
+            uint32_t *out = masks + (rowbase + tl) * BCD_MASK_WORDS;
+#pragma unroll
+            for (int j = 0; j < BCD_MASK_WORDS; j++) out[j] = m[j];
+        }
     }
-    // the 160-bit rows themselves (read by the chain kernel only for rows with more than 16 set bits)
-    uint32_t *out = masks + rowbase * BCD_MASK_WORDS;
-    for (int j = lane; j < tn * BCD_MASK_WORDS; j += 64) out[j] = st[(j / BCD_MASK_WORDS) * BCD_ROW_WORDS + j % BCD_MASK_WORDS];
 }
 
 // ------------------------------------------------------------------------------------------------ chains
