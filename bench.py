@@ -93,7 +93,7 @@ def main():
     for j in range(2):
         img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(2 * rank + j, 0))
         pairs.append((torch.from_numpy(img1).to(dev), torch.from_numpy(img2).to(dev)))
-    gather_buf = sharding.make_gather_buffers(flows[0].flow, world, rank) if world > 1 else None
+    gather_bufs = [sharding.make_gather_buffers(f.flow, world, rank) for f in flows] if world > 1 else None
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     bcd_events = []
@@ -115,7 +115,7 @@ def main():
                 bcd_events.append((e0, e1))
             flow = df.vratiKonacniFlow()
             if world > 1:
-                sharding.gather_flows(flow, gather_buf, rank)
+                sharding.gather_flows(flow, gather_bufs[i % P], rank)
         return flow
 
     for i in range(args.warmup):
@@ -162,8 +162,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # FETCH_SIZE + WRITE_SIZE per launch, rocprofv3 --pmc (one counter per pass, raw values,
-                         # profiles/r01_pmc_traffic.txt); expected from the access pattern: 0.94 GB (labels + bit rows)
-                         "traffic": (526595 + 33636) * 1024,
+                         # profiles/r01_pmc_traffic.txt; gfx950 FETCH_SIZE reports about half of wide reads); expected from the
+                         # access pattern: 1.14 GB (160 label slots x (8 B label + 24 B compat record) per visited pixel)
+                         "traffic": (597257 + 33598) * 1024,
                          "launch_ms": bcd_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "serial Viterbi chains (218-512 workgroups x 436-1024 dependent steps): latency-bound, "
                                  "not bandwidth-bound; launch_ms is measured with %d pairs in flight" % P},
