@@ -210,6 +210,37 @@ def make_fixture(name, H, W, cellh, cellw, seed, bcd_times=3, idx=6):
         dio.write_flo(path, fields[0])
         store["flo_parsed_by_reference"] = ns["read_flo_file"](path)
         store["flo_bytes"] = np.frombuffer(open(path, "rb").read(), np.uint8)
+    # G7 consumers: parovi.txt through the reference's napravi_parove.py (plain import), mean EPE and
+    # outlier percentage through the text of visualization.py's FlowImage/errorImage (cv2 absent -> empty stub; the
+    # colour map only feeds the optional image -> constant stub), which append to two txt files in the CWD.
+    sys.path.insert(0, REF)
+    try:
+        nap = importlib.import_module("napravi_parove")
+        with tempfile.TemporaryDirectory() as wd:
+            sp, tx = os.path.join(wd, "sparse_field.npy"), os.path.join(wd, "parovi.txt")
+            np.save(sp, store["sparse_t3"])
+            nap.parovi(sp, tx)
+            import gc; gc.collect()          # the reference never closes the file
+            store["parovi_t3_txt"] = np.frombuffer(open(tx, "rb").read(), np.uint8)
+    finally:
+        sys.path.remove(REF)
+    rng = np.random.default_rng(5)
+    gt3 = np.concatenate([gt, (rng.random(gt.shape[:2]) > 0.2)[..., None].astype(np.float64)], axis=-1)   # [dy,dx,valid]
+    ns = {"np": np, "os": os, "cv2": types.ModuleType("cv2"), "cmap": (lambda x: (0.0, 0.0, 0.0, 1.0))}
+    exec("\n".join(lines[30:156]), ns)        # class FlowImage ... def errorImage (visualization.py:31-156)
+    saved_cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as wd:
+        os.chdir(wd)
+        try:
+            np.save("gt.npy", gt3); np.save("test.npy", fields[0])
+            a_, b_ = ns["FlowImage"](), ns["FlowImage"]()
+            a_.ucitajFlow("gt.npy"); b_.ucitajFlow("test.npy")
+            ns["errorImage"](b_, a_)
+            store["epe_txt"] = open("srednja_greska.txt").read().strip()
+            store["outliers_txt"] = open("procenat_outliera.txt").read().strip()
+        finally:
+            os.chdir(saved_cwd)
+    store["gt_valid"] = gt3[..., 2].astype(np.uint8)
     out = os.path.join(ROOT, "tests", "golden", f"ref_{name}.npz")
     np.savez_compressed(out, **store)
     print("wrote", out, os.path.getsize(out), "bytes")
