@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Batch driver for BASELINE configs 3 and 4: forward + backward pass of every pair, sharded over the GPUs of one node
+(pass p -> rank p mod world, README.md:40 of the reference), RCCL gather of the flow fields on rank 0, then the
+forward/backward consistency check (postprocessing.py:123-135) per pair on rank 0.
+
+    python run_batch.py --pairs 8 --bcd-times 4 [--size 436x1024] [--thresh 10] [--out DIR]
+    python -m torch.distributed.run --nproc-per-node 8 run_batch.py --pairs 8 ...
+
+Inputs are synthetic pairs (synth.make_pair, seed 1000*pair); outputs per pair in DIR: the reference's flow .npy names
+for both directions, a .flo of the forward flow, sparse_field_<pair>.npy and parovi_<pair>.txt.
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = os.path.basename(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--pairs", type=int, default=1)
+    ap.add_argument("--bcd-times", type=int, default=4)
+    ap.add_argument("--size", default="436x1024")
+    ap.add_argument("--thresh", type=float, default=10.0)     # README.md:65 of the reference
+    ap.add_argument("--out", default=".")
+    a = ap.parse_args(argv)
+    import torch
+    import torch.distributed as dist
+    pipeline = importlib.import_module(PKG + ".pipeline")
+    sharding = importlib.import_module(PKG + ".sharding")
+    synth = importlib.import_module(PKG + ".synth")
+    flowio = importlib.import_module(PKG + ".flowio")
+    evaluate = importlib.import_module(PKG + ".evaluate")
+    H, W = (int(v) for v in a.size.lower().split("x"))
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    df = pipeline.DiscreteFlow(H, W, device=dev, seed=rank)
+    passes = [(pair, backward) for pair in range(a.pairs) for backward in (0, 1)]
+
+    def compute(desc):
+        pair, backward = desc
+        img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(pair, 0))
+        if backward:
+            img1, img2 = img2, img1
+        return df.run(img1, img2, a.bcd_times)
+
+    flows = sharding.run_passes(passes, compute, world, rank, df.flow)
+    if rank == 0:
+        os.makedirs(a.out, exist_ok=True)
+        for pair in range(a.pairs):
+            fwd, bwd = flows[2 * pair], flows[2 * pair + 1]
+            sparse = pipeline.fb_consistency(fwd, bwd, a.thresh).cpu().numpy()
+            for backward, f in ((0, fwd), (1, bwd)):
+                np.save(os.path.join(a.out, flowio.flow_name(pair, backward, a.bcd_times)), f.cpu().numpy().astype(np.float64))
+            flowio.write_flo(os.path.join(a.out, flowio.flow_name(pair, 0, a.bcd_times)[:-4] + ".flo"), fwd.cpu().numpy())
+            np.save(os.path.join(a.out, "sparse_field_%02d.npy" % pair), sparse)
+            evaluate.parovi(sparse, os.path.join(a.out, "parovi_%02d.txt" % pair))
+            print("pair %d: %.1f%% of the forward flow survives the consistency check" % (pair, 100.0 * sparse[..., 2].mean()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -277,3 +277,21 @@ def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
         flo = pkg("flowio").read_flo("Gotova flow slika 106 backward=0 posle %02d BCD.flo" % w)
         assert np.array_equal(flo, f[..., ::-1].astype(np.float32))
     assert np.array_equal(np.load("Bestlabels fajl slike 106 backward=0 posle 02 BCD.npy"), ref["bestlabels"])
+
+
+def test_batch_driver_config3(torch_, oracle, synth, tmp_path):
+    """BASELINE config 3 through the batch driver on one GPU: forward + backward + consistency, outputs on disk."""
+    import os
+    rb = pkg("run_batch")
+    H, W = 48, 64
+    rb.main(["--pairs", "1", "--bcd-times", "2", "--size", "%dx%d" % (H, W), "--thresh", "3", "--out", str(tmp_path)])
+    O = oracle
+    img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(0, 0))
+    ch, cw = pkg("pipeline").default_cells(H, W)
+    p = O.make_params(H, W, ch, cw, seed=0)
+    fwd = O.full_pass(p, img1, img2, 2)["flows"][-1]
+    bwd = O.full_pass(p, img2, img1, 2)["flows"][-1]
+    got = np.load(os.path.join(tmp_path, "sparse_field_00.npy"))
+    assert np.array_equal(got, O.fb_consistency(fwd, bwd, 3))
+    assert np.array_equal(np.load(os.path.join(tmp_path, "Gotova flow slika 100 backward=1 posle 02 BCD.npy")), bwd)
+    assert os.path.getsize(os.path.join(tmp_path, "parovi_00.txt")) > 0
