@@ -170,32 +170,35 @@ __device__ static inline void wave_min_lane0(Cand &pm)
 // Minimum of a 64-bit key over the wave (keys = bit patterns of positive doubles, which order like the doubles) and
 // the first lane that attains it: 4 DPP steps inside the rows of 16 lanes, the row leaders through v_readlane, then
 // one ballot.  Returns the minimum in every lane, *first_lane likewise.
-template <int CTRL> __device__ static inline unsigned long long key_dpp_min(unsigned long long x)
+template <int CTRL> __device__ static inline uint32_t u32_dpp_min(uint32_t x)
 {
-    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    // lanes without a source keep their own value (bound_ctrl = false, old = self); fuses into v_min_u32_dpp
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
     return o < x ? o : x;
 }
+// minimum of a 32-bit value over the wave, wave-uniform result: 4 DPP steps inside the rows of 16 lanes, then the row
+// leaders through v_readlane and scalar minima
+__device__ static inline uint32_t wave_u32_min(uint32_t x)
+{
+    x = u32_dpp_min<DPP_ROW_SHL1>(x);
+    x = u32_dpp_min<DPP_ROW_SHL2>(x);
+    x = u32_dpp_min<DPP_ROW_SHL4>(x);
+    x = u32_dpp_min<DPP_ROW_SHL8>(x);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+// Minimum of a 64-bit key over the wave (keys = bit patterns of positive doubles, which order like the doubles) and the
+// first lane that attains it: high words first, then the low words of the lanes that tie on the high word.
 __device__ static inline unsigned long long wave_key_min(unsigned long long key, int *first_lane)
 {
-    unsigned long long x = key;
-    x = key_dpp_min<DPP_ROW_SHL1>(x);
-    x = key_dpp_min<DPP_ROW_SHL2>(x);
-    x = key_dpp_min<DPP_ROW_SHL4>(x);
-    x = key_dpp_min<DPP_ROW_SHL8>(x);
-    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
-    unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, 0) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, 0);
-#pragma unroll
-    for (int r = 1; r < 4; r++) {
-        const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, 16 * r) << 32) |
-                                     (unsigned)__builtin_amdgcn_readlane(lo, 16 * r);
-        m = o < m ? o : m;
-    }
-    const unsigned long long hit = __ballot(key == m);
+    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    const uint32_t mh = wave_u32_min(hi);
+    const uint32_t ml = wave_u32_min(hi == mh ? lo : 0xFFFFFFFFu);
+    const unsigned long long hit = __ballot(hi == mh && lo == ml);
     *first_lane = __ffsll((long long)hit) - 1;
-    return m;
+    return ((unsigned long long)mh << 32) | ml;
 }
 
 // One thread per label: 192 threads (3 waves) cover up to DFLOW_MAX_LABELS labels.  Few, busy threads keep the
@@ -295,6 +298,25 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         // min over compatible previous labels (python bcd.py:163-176 / :198-219): walk the set bits of my mask row in
         // increasing k (strict '<' keeps the first minimum); the LDS reads of the next candidate are issued before the
         // current one is evaluated
+        // Everything that does not depend on the walk below is issued first, so that its LDS latency hides behind it:
+        // permmincost / permminlabel (python bcd.py:152-157) merged from the per-wave partials of the previous step
+        // (waves are in label order and every partial index is the first one inside its wave), and the unary term
+        // small = (lamda*lcost + s1) + s2 (python bcd.py:161-162).
+        Cand perm;
+        double small;
+        {
+            const unsigned long long p0 = permv[(cur ^ 1) * 4], p1 = permv[(cur ^ 1) * 4 + 1], p2 = permv[(cur ^ 1) * 4 + 2];
+            const int i0 = permi[(cur ^ 1) * 4], i1 = permi[(cur ^ 1) * 4 + 1], i2 = permi[(cur ^ 1) * 4 + 2];
+            const int ip = i + dirp, im = i - dirp;
+            const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
+            const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
+            unsigned long long pmn = p0; int pix_ = i0;
+            if (p1 < pmn) { pmn = p1; pix_ = i1; }
+            if (p2 < pmn) { pmn = p2; pix_ = i2; }
+            perm.v = __longlong_as_double((long long)pmn); perm.k = pix_;
+            small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
+        }
+
         double bestv = 1e300; int bestk = 0x7fffffff;
         const int cnt = act ? (int)rcnt : 0;
         {
@@ -356,26 +378,11 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
                 }
             }
         }
-        // waves are in label order and every partial index is the first one inside its wave
-        Cand perm;
-        {
-            const unsigned long long p0 = permv[(cur ^ 1) * 4], p1 = permv[(cur ^ 1) * 4 + 1], p2 = permv[(cur ^ 1) * 4 + 2];
-            const int i0 = permi[(cur ^ 1) * 4], i1 = permi[(cur ^ 1) * 4 + 1], i2 = permi[(cur ^ 1) * 4 + 2];
-            unsigned long long pmn = p0; int pix_ = i0;
-            if (p1 < pmn) { pmn = p1; pix_ = i1; }
-            if (p2 < pmn) { pmn = p2; pix_ = i2; }
-            perm.v = __longlong_as_double((long long)pmn); perm.k = pix_;
-        }
-
         unsigned long long key = ~0ull;
         if (act) {
-            const int ip = i + dirp, im = i - dirp;
-            const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
-            const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
             const bool found = bestk != 0x7fffffff;
             const double mincost = found ? bestv : perm.v;
             const int pl = found ? bestk : perm.k;
-            const double small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
             const double dpc = __dadd_rn(mincost, small);
             dpbuf[cur * BCD_LDS_LABELS + tl] = dpc;
             fpbuf[cur * BCD_LDS_LABELS + tl] = Fc;
