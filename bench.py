@@ -78,7 +78,10 @@ def main():
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run the process group is always created (also for one rank, which exercises the same
+    # RCCL gather path); a plain `python bench.py` runs without torch.distributed
+    use_dist = "RANK" in os.environ
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     cellh, cellw = pipeline.default_cells(H, W)
@@ -93,7 +96,7 @@ def main():
     for j in range(2):
         img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(2 * rank + j, 0))
         pairs.append((torch.from_numpy(img1).to(dev), torch.from_numpy(img2).to(dev)))
-    gather_bufs = [sharding.make_gather_buffers(f.flow, world, rank) for f in flows] if world > 1 else None
+    gather_bufs = [sharding.make_gather_buffers(f.flow, world, rank) for f in flows] if use_dist else None
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     bcd_events = []
@@ -114,7 +117,7 @@ def main():
                 e1.record()
                 bcd_events.append((e0, e1))
             flow = df.vratiKonacniFlow()
-            if world > 1:
+            if use_dist:
                 sharding.gather_flows(flow, gather_bufs[i % P], rank)
         return flow
 
@@ -123,7 +126,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -133,7 +136,7 @@ def main():
         step(i, True)
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -172,7 +175,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(synth)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
