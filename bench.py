@@ -24,7 +24,7 @@ PKG = "lk-s-2022-estimacija-pokreta_amd"
 
 H, W, BCD_TIMES = 436, 1024, 4
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: FP32 vector = FP32 matrix (f32-in MFMA) peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (the kNN screen runs on f16 MFMA)
 
 
 def knn_pairs(pich, picw, cellh, cellw, window=2):
@@ -52,6 +52,50 @@ def cpu_baseline(synth):
             "sample": "%dx%d crop-sized synthetic pair (1/16 frame), cells 27x64, bcd_times=%d, %.1f s; "
                       "C restatement of daisy i flann.py + python bcd.py (oracle/), exact kNN instead of FLANN"
                       % (w, h, BCD_TIMES, dt)}
+
+
+def stage_rooflines(torch, df, pair, cellh, cellw, reps=3):
+    """the three per-stage fractions and the end-to-end one, from one pair at a time on one stream
+    (no overlap with other pairs, unlike the timed region), HIP events between the stages, mean of `reps` passes."""
+    names = ["daisy", "knn", "neighbour", "pakovanje", "bcd", "labels_to_flow"]
+    acc = dict.fromkeys(names, 0.0)
+    st = torch.cuda.Stream(device=df.device)
+    for _ in range(reps):
+        with torch.cuda.stream(st):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+            evs[0].record()
+            df.load_pair(*pair); evs[1].record()
+            df.generisi(); evs[2].record()
+            df.nasumicni(); evs[3].record()
+            df.pakovanje(); evs[4].record()
+            df.ceoBCD(BCD_TIMES); evs[5].record()
+            df.vratiKonacniFlow(); evs[6].record()
+        st.synchronize()
+        for k, n in enumerate(names):
+            acc[n] += evs[k].elapsed_time(evs[k + 1]) / reps
+    N = H * W
+    daisy_bytes = 2 * N * (3 + 68 * 4)                               # 550 B/px/pass
+    knn_flops = 2 * 68 * knn_pairs(H, W, cellh, cellw)               # dense contraction of the +-2-cell window
+    knn_bytes = 2 * N * 272 + N * 125 * 8
+    bcd_bytes = BCD_TIMES * 2 * N * (150 * 4 + 150 * 4 + 16)         # 2.4 kB/px/sweep
+    total_ms = sum(acc.values())
+    gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
+    return {
+        "measured": "one pair at a time on one stream, mean of %d passes" % reps,
+        "ms": {n: round(acc[n], 4) for n in names}, "ms_total": round(total_ms, 4),
+        "daisy": {"bound": "hbm", "bytes": daisy_bytes, "achieved": gbs(daisy_bytes, acc["daisy"]), "unit": "GB/s",
+                  "peak": HBM_PEAK_GBS, "frac": gbs(daisy_bytes, acc["daisy"]) / HBM_PEAK_GBS},
+        "knn": {"bound": "mfma", "flops": knn_flops, "achieved": knn_flops / (acc["knn"] * 1e-3) / 1e12,
+                "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TFLOPS,
+                "frac": knn_flops / (acc["knn"] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                "note": "f16 MFMA screen with a rigorous error bound + exact f32 re-ranking of the survivors; "
+                        "flops are the algorithmic 2*68 per (query, candidate) pair"},
+        "bcd": {"bound": "hbm", "bytes": bcd_bytes, "achieved": gbs(bcd_bytes, acc["bcd"]), "unit": "GB/s",
+                "peak": HBM_PEAK_GBS, "frac": gbs(bcd_bytes, acc["bcd"]) / HBM_PEAK_GBS},
+        "end_to_end": {"bound": "hbm", "bytes": daisy_bytes + knn_bytes + bcd_bytes,
+                       "achieved": gbs(daisy_bytes + knn_bytes + bcd_bytes, total_ms), "unit": "GB/s",
+                       "peak": HBM_PEAK_GBS, "frac": gbs(daisy_bytes + knn_bytes + bcd_bytes, total_ms) / HBM_PEAK_GBS},
+    }
 
 
 def main():
@@ -172,6 +216,7 @@ def main():
                          "note": "serial Viterbi chains (218-512 workgroups x 436-1024 dependent steps): latency-bound, "
                                  "not bandwidth-bound; launch_ms is measured with %d pairs in flight" % P},
         }
+        out["roofline"]["stages"] = stage_rooflines(torch, flows[0], pairs[0], cellh, cellw)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(synth)
         print(json.dumps(out), flush=True)

@@ -88,24 +88,24 @@ int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, cons
                               const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream);
 
 /* Builds the compat bit matrices of pakovanje (daisy i flann.py:256-309) into the workspace, in the layout the chain
- * kernel reads (only the two neighbours a pixel's chains use).  Must be called after the proposals are final (after
- * dflow_neighbour_proposals / an upload) and before dflow_bcd_phase / dflow_bcd_sweep; the matrices stay valid until
+ * kernel reads: per pixel, per chain direction and per label one record with the compatible labels of the predecessor
+ * on that chain, their pairwise costs, and the label's own flow and data cost (what ucitajSvePodatkeDoBCD,
+ * python bcd.py:67-81, loads for bcd()).  Must be called after proposals and lcosts are final (after
+ * dflow_neighbour_proposals / an upload) and before dflow_bcd_phase / dflow_bcd_sweep; the records stay valid until
  * another dflow_* stage call (daisy, knn) reuses the same workspace. */
-int dflow_bcd_prepare(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop,
+int dflow_bcd_prepare(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts, const int32_t *d_nprop,
                       void *d_ws, size_t ws_bytes, void *stream);
 
 /* One of the four loops of ceoBCD's body, python bcd.py:265-277 (phase 0 even columns top->bottom,
  * 1 even rows right->left, 2 odd columns bottom->top, 3 odd rows left->right); every chain is one call of
- * bcd(), python bcd.py:101-257, reading the bit matrices dflow_bcd_prepare left in the workspace.
+ * bcd(), python bcd.py:101-257, reading the records dflow_bcd_prepare left in the workspace (label costs included).
  * Updates d_bestlabels in place. */
-int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts,
-                    const int32_t *d_nprop, int32_t *d_bestlabels, int32_t phase,
-                    void *d_ws, size_t ws_bytes, void *stream);
+int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop,
+                    int32_t *d_bestlabels, int32_t phase, void *d_ws, size_t ws_bytes, void *stream);
 
 /* One iteration of ceoBCD's loop (all four phases), python bcd.py:264-277. */
-int dflow_bcd_sweep(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts,
-                    const int32_t *d_nprop, int32_t *d_bestlabels,
-                    void *d_ws, size_t ws_bytes, void *stream);
+int dflow_bcd_sweep(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop,
+                    int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream);
 
 /* vratiKonacniFlow, python bcd.py:90-95 / daisy i flann.py:192-197. */
 int dflow_labels_to_flow(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_bestlabels,

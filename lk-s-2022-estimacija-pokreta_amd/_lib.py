@@ -52,9 +52,9 @@ def lib():
         L.dflow_daisy.argtypes = [pp, vp, vp, vp, sz, vp]
         L.dflow_knn_proposals.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.dflow_neighbour_proposals.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
-        L.dflow_bcd_prepare.argtypes = [pp, vp, vp, vp, sz, vp]
-        L.dflow_bcd_phase.argtypes = [pp, vp, vp, vp, vp, i32, vp, sz, vp]
-        L.dflow_bcd_sweep.argtypes = [pp, vp, vp, vp, vp, vp, sz, vp]
+        L.dflow_bcd_prepare.argtypes = [pp, vp, vp, vp, vp, sz, vp]
+        L.dflow_bcd_phase.argtypes = [pp, vp, vp, vp, i32, vp, sz, vp]
+        L.dflow_bcd_sweep.argtypes = [pp, vp, vp, vp, vp, sz, vp]
         L.dflow_labels_to_flow.argtypes = [pp, vp, vp, vp, vp]
         L.dflow_fb_consistency.argtypes = [pp, vp, vp, C.c_float, vp, vp]
         for n in SYMBOLS[4:]:

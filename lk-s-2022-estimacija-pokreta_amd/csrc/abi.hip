@@ -102,28 +102,28 @@ int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, cons
     return launch_neighbour(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, (hipStream_t)stream);
 }
 
-int dflow_bcd_prepare(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop, void *d_ws, size_t ws_bytes,
-                      void *stream)
+int dflow_bcd_prepare(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts, const int32_t *d_nprop,
+                      void *d_ws, size_t ws_bytes, void *stream)
 {
     int rc = dflow_check_params(p); if (rc) return rc;
-    CHECK_PTR(d_proposals); CHECK_PTR(d_nprop); CHECK_WS(bcd_ws_bytes(p));
-    return launch_bcd_prepare(p, d_proposals, d_nprop, d_ws, (hipStream_t)stream);
+    CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_WS(bcd_ws_bytes(p));
+    return launch_bcd_prepare(p, d_proposals, d_lcosts, d_nprop, d_ws, (hipStream_t)stream);
 }
 
-int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts, const int32_t *d_nprop,
-                    int32_t *d_bestlabels, int32_t phase, void *d_ws, size_t ws_bytes, void *stream)
+int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop, int32_t *d_bestlabels,
+                    int32_t phase, void *d_ws, size_t ws_bytes, void *stream)
 {
     int rc = dflow_check_params(p); if (rc) return rc;
-    CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels); CHECK_WS(bcd_ws_bytes(p));
+    CHECK_PTR(d_proposals); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels); CHECK_WS(bcd_ws_bytes(p));
     if (phase < 0 || phase > 3) return dflow_set_error(DFLOW_EINVAL, "phase=%d outside [0,3]", phase);
-    return launch_bcd_phase(p, d_proposals, d_lcosts, d_nprop, d_bestlabels, phase, d_ws, (hipStream_t)stream);
+    return launch_bcd_phase(p, d_proposals, d_nprop, d_bestlabels, phase, d_ws, (hipStream_t)stream);
 }
 
-int dflow_bcd_sweep(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts, const int32_t *d_nprop,
-                    int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream)
+int dflow_bcd_sweep(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop, int32_t *d_bestlabels,
+                    void *d_ws, size_t ws_bytes, void *stream)
 {
     for (int ph = 0; ph < 4; ph++) {
-        int rc = dflow_bcd_phase(p, d_proposals, d_lcosts, d_nprop, d_bestlabels, ph, d_ws, ws_bytes, stream);
+        int rc = dflow_bcd_phase(p, d_proposals, d_nprop, d_bestlabels, ph, d_ws, ws_bytes, stream);
         if (rc) return rc;
     }
     return DFLOW_OK;

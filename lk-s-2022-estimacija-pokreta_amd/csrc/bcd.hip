@@ -3,24 +3,26 @@
 //
 // Two kernels:
 //   bcd_masks_kernel   once per pass (the proposals do not change during the sweeps): for every pixel p and both of
-//                      its chains (column chain / row chain) the 160-bit rows mask[tl] = { k : tpsi > |dy-dy'|+|dx-dx'|
+//                      its chains (column chain / row chain) and every label tl of p, the set { k : tpsi > |dy-dy'|+|dx-dx'|
 //                      between label tl of p and label k of p's predecessor on that chain } -- the reference's
 //                      packedksets (Q8), restricted to the two neighbours that are ever used and already transposed
-//                      for the direction in which the chain runs.  lanes = predecessor labels, one v_sad_u16 +
-//                      v_cmp per 64 pairs, the wave ballot is the mask word.
+//                      for the direction in which the chain runs.  lanes = labels of p, the predecessor's labels are
+//                      wave-uniform: one v_sad_u16 + one v_alignbit per pair builds the 160-bit row in registers.  What
+//                      the chain kernel reads every step is a 32-byte record per row: the first 16 members as bytes,
+//                      their pairwise costs as nibbles, and the label's own flow and data cost.
 //   bcd_chain_kernel   one workgroup per chain of a phase (all chains of a phase are independent: a chain reads and
-//                      writes only its own image line).  192 threads, one per label; a lane walks the set bits of
-//                      its label's mask row (only compatible predecessors cost float64 work), float64 arithmetic in
-//                      the reference's association order
-//                      (dp = mincost + ((lamda*lcost + s1) + s2); first-index ties everywhere, Q9-Q11).
-//                      dp / predecessor flows live in LDS (double buffered), label data and mask rows are prefetched
-//                      three steps ahead, back-pointers go to the workspace as uint8 and are walked chunk-wise from LDS.
+//                      writes only its own image line).  192 threads, one per label; a lane walks its label's list
+//                      (only compatible predecessors cost float64 work), float64 arithmetic in the reference's
+//                      association order (dp = mincost + ((lamda*lcost + s1) + s2); first-index ties everywhere, Q9-Q11).
+//                      dp lives in LDS (double buffered), the records are prefetched three steps ahead, back-pointers
+//                      go to the workspace as uint8 and are walked chunk-wise from LDS.
 #include "dflow_common.h"
 
 #define BCD_THREADS 192
-#define BCD_MASK_WORDS 5                 // 160 bits per label row
-#define BCD_REC_WORDS 6                  // row record the chain kernel reads every step: 4 words = the first 16 set bits as
-                                         // bytes (0xFF = none), 1 word = popcount, 1 pad; the 5 mask words live in a second array
+#define BCD_MASK_WORDS 5                 // 160 bits per label row (kept in HBM only for rows with more than 16 members)
+#define BCD_REC_WORDS 8                  // row record: 4 words = the first 16 members as bytes, increasing (0xFF = none);
+                                         // 2 words = their pairwise costs |dy-dy'|+|dx-dx'| (< tpsi <= 8) as nibbles, bit 63 =
+                                         // "more than 16 members"; 1 word = the label's biased flow; 1 word = its data cost
 #define BCD_LIST 16
 #define BCD_LDS_LABELS 256
 #define BCD_TB_STEPS 128                 // traceback chunk (steps) staged in LDS
@@ -37,11 +39,12 @@ __device__ static inline void chain_geom(int phase, int chain, int H, int W, int
 // ------------------------------------------------------------------------------------------------ masks
 // grid: one wave per (pixel, dir); dir 0 = the pixel's column chain, dir 1 = its row chain.
 __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, int tpsi, const uint32_t *__restrict__ proposals,
-                                                        const int32_t *__restrict__ nprop, uint32_t *__restrict__ masks,
-                                                        uint32_t *__restrict__ recs)
+                                                        const float *__restrict__ lcosts, const int32_t *__restrict__ nprop,
+                                                        uint32_t *__restrict__ masks, uint32_t *__restrict__ recs)
 {
-    const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t s_cols[4][192];                      // the predecessor's biased labels, per wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long item = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv);
     if (item >= 2LL * H * W) return;
     const int dir = (int)(item & 1);
     const int pix = (int)(item >> 1);
@@ -49,63 +52,87 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
     // predecessor on the chain (python bcd.py:265-277): even columns run down, odd columns up, even rows leftwards, odd rows rightwards
     int py = y, px = x;
     if (dir == 0) py = (x & 1) ? y + 1 : y - 1; else px = (y & 1) ? x - 1 : x + 1;
-    if (py < 0 || py >= H || px < 0 || px >= W) return;       // chain start: no transition into this pixel
-    const int ppix = py * W + px;
-    const int tn = nprop[pix], pn = nprop[ppix];
+    const bool start = py < 0 || py >= H || px < 0 || px >= W;     // chain start: no transition into this pixel
+    const int ppix = start ? pix : py * W + px;
+    const int tn = nprop[pix], pn = start ? 0 : nprop[ppix];
     uint32_t fp[3], fcv[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int k = lane + 64 * j;
         fp[j] = k < pn ? flow_bias(proposals[(size_t)ppix * LP + k]) : 0u;   // 0: far from every biased flow
         fcv[j] = k < tn ? flow_bias(proposals[(size_t)pix * LP + k]) : 0u;
+        s_cols[wv][k] = fp[j];
+    }
+    // lanes = labels of this pixel (three groups of 64), predecessor labels come one by one as wave-uniform scalars:
+    // D = sad + (2^31 - tpsi) has bit 31 set iff the pair is NOT compatible, v_alignbit shifts that bit into the row
+    // word.  Columns run downwards inside each 32-bit word so that column c ends up in bit c.
+    const uint32_t kbias = 0x80000000u - (uint32_t)tpsi;
+    uint32_t m[3][BCD_MASK_WORDS];
+#pragma unroll
+    for (int j = 0; j < BCD_MASK_WORDS; j++) {
+        m[0][j] = m[1][j] = m[2][j] = 0xFFFFFFFFu;
+        if (32 * j < pn) {
+#pragma unroll
+            for (int cc = 31; cc >= 0; cc--) {
+                const int c = 32 * j + cc;
+                const uint32_t col = (uint32_t)__builtin_amdgcn_readlane((int)fp[c >> 6], c & 63);
+                m[0][j] = __builtin_amdgcn_alignbit(m[0][j], __builtin_amdgcn_sad_u16(col, fcv[0], kbias), 31);
+                m[1][j] = __builtin_amdgcn_alignbit(m[1][j], __builtin_amdgcn_sad_u16(col, fcv[1], kbias), 31);
+                m[2][j] = __builtin_amdgcn_alignbit(m[2][j], __builtin_amdgcn_sad_u16(col, fcv[2], kbias), 31);
+            }
+        }
     }
     const size_t rowbase = ((size_t)pix * 2 + dir) * (size_t)LP;
 #pragma unroll
     for (int grp = 0; grp < 3; grp++) {
-        const int nrows = min(64, tn - 64 * grp);          // rows 64 grp .. 64 grp + nrows - 1 (wave-uniform)
-        if (nrows <= 0) break;
-        // lanes = predecessor labels: one v_sad_u16 + compare per 64 pairs, the ballot is a mask word; the 5
-        // words of row r are deposited in lane r, so that afterwards lane = row
-        uint32_t m[BCD_MASK_WORDS] = {0u, 0u, 0u, 0u, 0u};
-        for (int r = 0; r < nrows; r++) {
-            const uint32_t fc = __builtin_amdgcn_readlane(fcv[grp], r);      // label 64 grp + r of this pixel
-            const unsigned long long m0 = __ballot(flow_l1_biased(fc, fp[0]) < (uint32_t)tpsi);
-            const unsigned long long m1 = __ballot(flow_l1_biased(fc, fp[1]) < (uint32_t)tpsi);
-            const unsigned long long m2 = __ballot(flow_l1_biased(fc, fp[2]) < (uint32_t)tpsi);
-            const bool mine = lane == r;                       // deposit the 5 words of row r in lane r
-            m[0] = mine ? (uint32_t)m0 : m[0];
-            m[1] = mine ? (uint32_t)(m0 >> 32) : m[1];
-            m[2] = mine ? (uint32_t)m1 : m[2];
-            m[3] = mine ? (uint32_t)(m1 >> 32) : m[3];
-            m[4] = mine ? (uint32_t)m2 : m[4];
-        }
-        if (lane < nrows) {
-            // lane = row: the first 16 set bits as a byte list (what the chain kernel reads every step) and the popcount
-            const int tl = 64 * grp + lane;
+        const int tl = 64 * grp + lane;
+        if (64 * grp >= tn) break;                           // wave-uniform
+        if (tl < tn) {
+            // the first 16 members as bytes and their pairwise costs as nibbles.  Both lists are shift registers filled
+            // from the top (position-independent inserts) and moved down to their final place afterwards.
+            uint32_t w[BCD_MASK_WORDS];
             int cnt = 0;
 #pragma unroll
-            for (int j = 0; j < BCD_MASK_WORDS; j++) cnt += __popc(m[j]);
-            uint32_t l[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            for (int j = 0; j < BCD_MASK_WORDS; j++) { w[j] = ~m[grp][j]; cnt += __popc(w[j]); }
+            uint32_t l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu, l2 = 0xFFFFFFFFu, l3 = 0xFFFFFFFFu, p0 = 0u, p1 = 0u;
             int n = 0;
+            const uint32_t me = fcv[grp];
 #pragma unroll
             for (int j = 0; j < BCD_MASK_WORDS; j++) {
-                uint32_t w = m[j];
-                while (w && n < BCD_LIST) {
-                    const uint32_t k = 32 * j + __ffs(w) - 1; w &= w - 1;
-                    const uint32_t sh = 8 * (n & 3), clr = ~(0xFFu << sh), val = k << sh;
-                    if (n < 4) l[0] = (l[0] & clr) | val; else if (n < 8) l[1] = (l[1] & clr) | val;
-                    else if (n < 12) l[2] = (l[2] & clr) | val; else l[3] = (l[3] & clr) | val;
+                uint32_t ww = w[j];
+                while (ww && n < BCD_LIST) {
+                    const uint32_t k = 32 * j + __ffs(ww) - 1; ww &= ww - 1;
+                    const uint32_t psi = flow_l1_biased(me, s_cols[wv][k]);
+                    l0 = __builtin_amdgcn_alignbit(l1, l0, 8); l1 = __builtin_amdgcn_alignbit(l2, l1, 8);
+                    l2 = __builtin_amdgcn_alignbit(l3, l2, 8); l3 = __builtin_amdgcn_alignbit(k, l3, 8);
+                    p0 = __builtin_amdgcn_alignbit(p1, p0, 4); p1 = __builtin_amdgcn_alignbit(psi, p1, 4);
                     n++;
                 }
             }
+            // n entries sit in the top n bytes / nibbles: shift right by 16-n places, 0xFF / 0 come in from the top
+            {
+                const int sh = BCD_LIST - n;                  // 0..16
+                if (sh & 1) { l0 = __builtin_amdgcn_alignbit(l1, l0, 8); l1 = __builtin_amdgcn_alignbit(l2, l1, 8);
+                              l2 = __builtin_amdgcn_alignbit(l3, l2, 8); l3 = __builtin_amdgcn_alignbit(0xFFFFFFFFu, l3, 8); }
+                if (sh & 2) { l0 = __builtin_amdgcn_alignbit(l1, l0, 16); l1 = __builtin_amdgcn_alignbit(l2, l1, 16);
+                              l2 = __builtin_amdgcn_alignbit(l3, l2, 16); l3 = __builtin_amdgcn_alignbit(0xFFFFFFFFu, l3, 16); }
+                if (sh & 4) { l0 = l1; l1 = l2; l2 = l3; l3 = 0xFFFFFFFFu; }
+                if (sh & 8) { l0 = l2; l1 = l3; l2 = 0xFFFFFFFFu; l3 = 0xFFFFFFFFu; }
+                if (sh & 16) { l0 = l1 = l2 = l3 = 0xFFFFFFFFu; }
+                unsigned long long pp = ((unsigned long long)p1 << 32) | p0;
+                pp = n ? pp >> (4 * sh) : 0ull;
+                p0 = (uint32_t)pp; p1 = (uint32_t)(pp >> 32);
+            }
+            if (cnt > BCD_LIST) p1 |= 0x80000000u;
             uint32_t *rec = recs + (rowbase + tl) * BCD_REC_WORDS;
-            *reinterpret_cast<uint2 *>(rec) = make_uint2(l[0], l[1]);
-            *reinterpret_cast<uint2 *>(rec + 2) = make_uint2(l[2], l[3]);
-            *reinterpret_cast<uint2 *>(rec + 4) = make_uint2((uint32_t)cnt, 0u);
-            // the 160-bit row itself (read by the chain kernel only for rows with more than 16 set bits)
-            uint32_t *out = masks + (rowbase + tl) * BCD_MASK_WORDS;
+            *reinterpret_cast<uint4 *>(rec) = make_uint4(l0, l1, l2, l3);
+            *reinterpret_cast<uint4 *>(rec + 4) = make_uint4(p0, p1, me, __float_as_uint(lcosts[(size_t)pix * LP + tl]));
+            if (cnt > BCD_LIST) {
+                // the 160-bit row itself: read by the chain kernel only for rows with more than 16 members
+                uint32_t *out = masks + (rowbase + tl) * BCD_MASK_WORDS;
 #pragma unroll
-            for (int j = 0; j < BCD_MASK_WORDS; j++) out[j] = m[j];
+                for (int j = 0; j < BCD_MASK_WORDS; j++) out[j] = w[j];
+            }
         }
     }
 }
@@ -115,7 +142,6 @@ struct BcdArgs {
     int H, W, LP, tpsi, phase;
     double lamda;
     const uint32_t *proposals;
-    const float *lcosts;
     const int32_t *nprop;
     int32_t *bestlabels;
     const uint32_t *masks, *recs;
@@ -201,17 +227,65 @@ __device__ static inline unsigned long long wave_key_min(unsigned long long key,
     return ((unsigned long long)mh << 32) | ml;
 }
 
+
+// minimum of a 32-bit value over the wave, wave-uniform result: 4 fused DPP minima inside the rows of 16 lanes (lanes
+// without a source keep their own value; s_nop 1 = the two wait states a DPP read of a fresh VALU result needs), then
+// the row leaders through v_readlane and scalar minima
+__device__ static inline uint32_t wave_u32_min_asm(uint32_t x)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(x));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+__device__ static inline unsigned long long wave_key_min_asm(unsigned long long key, int *first_lane)
+{
+    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    const uint32_t mh = wave_u32_min_asm(hi);
+    const uint32_t ml = wave_u32_min_asm(hi == mh ? lo : 0xFFFFFFFFu);
+    const unsigned long long hit = __ballot(hi == mh && lo == ml);
+    *first_lane = __ffsll((long long)hit) - 1;
+    return ((unsigned long long)mh << 32) | ml;
+}
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+#ifdef BCD_PROF
+// diagnostic build only (scratch/): per-wave cycle stamps of the step sections of block 0, summed over the chain
+__device__ unsigned long long g_bcd_prof[3][8];
+extern "C" void dflow_debug_bcd_prof(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bcd_prof), sizeof(g_bcd_prof)); }
+extern "C" void dflow_debug_bcd_prof_reset() { unsigned long long z[24] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bcd_prof), z, sizeof(z)); }
+#define PROF_DECL unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt = 0;
+#define PROF_START pt = __builtin_amdgcn_s_memtime();
+#define PROF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc[k] += n_ - pt; pt = n_; }
+#else
+#define PROF_DECL
+#define PROF_START
+#define PROF(k)
+#endif
+
 // One thread per label: 192 threads (3 waves) cover up to DFLOW_MAX_LABELS labels.  Few, busy threads keep the
-// per-step instruction count (and with it the latency of the serial chain) low.
+// per-step instruction count low: every wave is alone on its SIMD, so a step costs (instructions x issue cycles).
 __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *dpbuf = (double *)smem;                                   // [2][BCD_LDS_LABELS]; entries >= 160 stay +inf (list sentinel 0xFF)
-    unsigned long long *permv = (unsigned long long *)(dpbuf + 2 * BCD_LDS_LABELS);   // [2][4] per-wave minima of bits(tpsi + dp)
-    uint32_t *fpbuf = (uint32_t *)(permv + 2 * 4);                    // [2][BCD_LDS_LABELS] biased flows
-    int *permi = (int *)(fpbuf + 2 * BCD_LDS_LABELS);               // [2][4]; permi[8] = traceback hand-over
-    uint8_t *tb = (uint8_t *)(permi + 2 * 4 + 4);                     // [BCD_TB_STEPS][LP] traceback chunk (16-byte aligned)
-    uint32_t *bestf = (uint32_t *)(tb + BCD_TB_STEPS * a.LP);         // [len] biased flow of each chain pixel's current label
+    // static LDS has compile-time addresses, so the offsets fold into the ds_read immediates
+    __shared__ double s_dp[2 * BCD_LDS_LABELS];                               // [2][labels]; entries >= 160 stay +inf (list sentinel 0xFF)
+    __shared__ uint32_t s_fp[2 * BCD_LDS_LABELS];                             // [2][labels] biased flows (rows with more than 16 members only)
+    __shared__ unsigned long long permv[2 * 4];                               // per-wave minima of bits(tpsi + dp)
+    __shared__ int permi[2 * 4 + 4];                                          // their labels; [8] = traceback hand-over
+    __shared__ __attribute__((aligned(16))) uint8_t tb[BCD_TB_STEPS * DFLOW_MAX_LABELS];   // traceback chunk
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    uint32_t *bestf = s_dyn + 1;                                      // [-1..len] biased flow of each chain pixel's current label
     int *tnl;                                                         // [len] nprop of each chain pixel (set below)
     int *s_label = permi + 8;
 
@@ -231,30 +305,29 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     const uint32_t tpsi = (uint32_t)a.tpsi;
     const double tpsi_d = (double)a.tpsi;
 
-    tnl = (int *)(bestf + len);
-    for (int i = tid; i < 2 * BCD_LDS_LABELS; i += BCD_THREADS) { dpbuf[i] = 1e300; fpbuf[i] = 0u; }
+    tnl = (int *)(bestf + len + 1);
+    for (int i = tid; i < 2 * BCD_LDS_LABELS; i += BCD_THREADS) { s_dp[i] = 1e300; s_fp[i] = 0u; }
     for (int i = tid; i < len; i += BCD_THREADS) {
         int pix = pix0 + i * pstep;
         bestf[i] = flow_bias(a.proposals[(size_t)pix * LP + a.bestlabels[pix]]);
         tnl[i] = a.nprop[pix];      // a wave-uniform global load inside the step loop would stall every step (it is
                                     // moved to an SGPR at once); the label counts are read from LDS instead
     }
+    if (tid == 0) { bestf[-1] = 0u; bestf[len] = 0u; }       // read, never used (the limit of that side term is 0)
     __syncthreads();
 
-    uint8_t *back = a.back + (size_t)chain * len * LP;
-
-    // Per-step inputs of this thread, prefetched three steps ahead.  All loads are unconditional (rows are LP wide;
-    // mask rows of unused labels hold garbage that is masked at use), so nothing in a step waits for a load issued
-    // in the same step.
-    struct StepIn { uint32_t F; float lc; uint4 rl; uint32_t cnt; };   // rl = byte list of the first 16 compatible labels
+    // Per-step inputs of this thread = its label's 32-byte record (see BCD_REC_WORDS), prefetched three steps ahead.
+    // All loads are unconditional (rows are LP wide; records of unused labels hold garbage that indexes inside the LDS
+    // arrays and is never written back), so nothing in a step waits for a load issued in the same step.
+    struct StepIn { uint4 rl; uint4 px; };   // rl = byte list; px = {cost nibbles lo, hi | more flag, biased flow, data cost}
+    const uint32_t offr = (uint32_t)tl * (BCD_REC_WORDS * 4u);
+    const size_t rowbytesr = (size_t)LP * (BCD_REC_WORDS * 4u);
     auto fetch = [&](int i) {
         StepIn r;
-        const int pix = pix0 + min(i, len - 1) * pstep;
-        r.F = flow_bias(a.proposals[(size_t)pix * LP + tl]);
-        r.lc = a.lcosts[(size_t)pix * LP + tl];
-        const uint32_t *rec = a.recs + (((size_t)pix * 2 + dir) * LP + tl) * BCD_REC_WORDS;
-        const uint2 r01 = *reinterpret_cast<const uint2 *>(rec), r23 = *reinterpret_cast<const uint2 *>(rec + 2);
-        r.rl = make_uint4(r01.x, r01.y, r23.x, r23.y); r.cnt = rec[4];
+        const size_t pix = (size_t)(pix0 + min(i, len - 1) * pstep);
+        const char *pr = (const char *)a.recs + (pix * 2 + dir) * rowbytesr;
+        r.rl = *reinterpret_cast<const uint4 *>(pr + offr);
+        r.px = *reinterpret_cast<const uint4 *>(pr + offr + 16);
         return r;
     };
     const StepIn S0 = fetch(0);
@@ -262,54 +335,56 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
 
     // ---- chain start: dp[0,tl] = (s1 + s2) + lamda*lcost   (python bcd.py:118-120)
     {
-        const uint32_t Fc = S0.F;
+        const uint32_t Fc = S0.px.z;
         const int ip = dirp, im = -dirp;
         const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
         const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
         unsigned long long key = ~0ull;
         if (owner && tl < tnl[0]) {
-            const double d0 = __dadd_rn((double)(s1 + s2), __dmul_rn(a.lamda, (double)S0.lc));
-            dpbuf[tl] = d0;
-            fpbuf[tl] = Fc;
+            const double d0 = __dadd_rn((double)(s1 + s2), __dmul_rn(a.lamda, (double)__uint_as_float(S0.px.w)));
+            s_dp[tl] = d0;
+            s_fp[tl] = Fc;
             key = (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, d0));
         }
         int fl;
-        const unsigned long long m = wave_key_min(key, &fl);
+        const unsigned long long m = wave_key_min_asm(key, &fl);
         if (lane == 0) { permv[wave] = m; permi[wave] = wave * 64 + fl; }
     }
     __syncthreads();
 
-    int cur = 1;
+    PROF_DECL
     int pn = tnl[0];
-    // One step of the chain.  `in` is consumed first and then refilled with the inputs of step i+3: the three slots are
-    // used round-robin by the 3x unrolled loop below, so prefetched registers are never copied while their loads are
-    // still in flight (a register rotation A=B, B=C would make every step wait for the loads it has just issued).
-    auto step = [&](const int i, StepIn &in) __attribute__((always_inline)) {
+    uint8_t *backp = a.back + (size_t)chain * len * LP + tl;          // + i*LP per step
+    // One step of the chain; CUR (compile-time) is the LDS buffer this step writes, CUR^1 holds the previous pixel.  `in`
+    // is consumed first and then refilled with the inputs of step i+3: the three slots are used round-robin by the 6x
+    // unrolled loop below, so prefetched registers are never copied while their loads are still in flight (a register
+    // rotation A=B, B=C would make every step wait for the loads it has just issued).
+    auto step = [&](auto curc, const int i, StepIn &in) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(curc)::value;
+        const char *prev = reinterpret_cast<const char *>(s_dp + (CUR ^ 1) * BCD_LDS_LABELS);
+        const uint32_t *fprev = s_fp + (CUR ^ 1) * BCD_LDS_LABELS;
+        PROF_START
         const int tn = tnl[i];
-        const uint32_t Fc = in.F;
-        const float lc = in.lc;
+        const uint4 rl = in.rl;
+        const uint32_t pw0 = in.px.x, pw1 = in.px.y, Fc = in.px.z;
+        const float lc = __uint_as_float(in.px.w);
         const bool act = owner && tl < tn;
-        const uint4 rl = in.rl; const uint32_t rcnt = in.cnt;
-        const size_t rowidx = ((size_t)(pix0 + i * pstep) * 2 + dir) * LP + tl;
         in = fetch(i + 3);
-        const double *dp = dpbuf + (cur ^ 1) * BCD_LDS_LABELS;
-        const uint32_t *fp = fpbuf + (cur ^ 1) * BCD_LDS_LABELS;
+        PROF(0)
 
-        // min over compatible previous labels (python bcd.py:163-176 / :198-219): walk the set bits of my mask row in
-        // increasing k (strict '<' keeps the first minimum); the LDS reads of the next candidate are issued before the
-        // current one is evaluated
         // Everything that does not depend on the walk below is issued first, so that its LDS latency hides behind it:
         // permmincost / permminlabel (python bcd.py:152-157) merged from the per-wave partials of the previous step
         // (waves are in label order and every partial index is the first one inside its wave), and the unary term
-        // small = (lamda*lcost + s1) + s2 (python bcd.py:161-162).
+        // small = (lamda*lcost + s1) + s2 (python bcd.py:161-162; a side neighbour outside the chain contributes 0).
         Cand perm;
         double small;
         {
-            const unsigned long long p0 = permv[(cur ^ 1) * 4], p1 = permv[(cur ^ 1) * 4 + 1], p2 = permv[(cur ^ 1) * 4 + 2];
-            const int i0 = permi[(cur ^ 1) * 4], i1 = permi[(cur ^ 1) * 4 + 1], i2 = permi[(cur ^ 1) * 4 + 2];
+            const unsigned long long p0 = permv[(CUR ^ 1) * 4], p1 = permv[(CUR ^ 1) * 4 + 1], p2 = permv[(CUR ^ 1) * 4 + 2];
+            const int i0 = permi[(CUR ^ 1) * 4], i1 = permi[(CUR ^ 1) * 4 + 1], i2 = permi[(CUR ^ 1) * 4 + 2];
             const int ip = i + dirp, im = i - dirp;
-            const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
-            const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
+            const uint32_t lim1 = (ip >= 0 && ip < len) ? tpsi : 0u, lim2 = (im >= 0 && im < len) ? tpsi : 0u;
+            const uint32_t s1 = min(lim1, flow_l1_biased(Fc, bestf[ip]));
+            const uint32_t s2 = min(lim2, flow_l1_biased(Fc, bestf[im]));
             unsigned long long pmn = p0; int pix_ = i0;
             if (p1 < pmn) { pmn = p1; pix_ = i1; }
             if (p2 < pmn) { pmn = p2; pix_ = i2; }
@@ -317,35 +392,40 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
             small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
         }
 
-        double bestv = 1e300; int bestk = 0x7fffffff;
-        const int cnt = act ? (int)rcnt : 0;
+        // min over compatible previous labels (python bcd.py:163-176 / :198-219) in increasing k (strict '<' keeps the
+        // first minimum).  The first 16 compatible predecessors of every row come as a byte list in increasing k (0xFF =
+        // none, which reads the +inf tail of dp) together with their pairwise costs; the LDS reads of 8 candidates are
+        // issued together.  Candidates are tracked by their dp offset 8 k.
+        PROF(1)
+        double bestv = 1e300; uint32_t besta = 0x7fffffffu;
+        const bool more8 = act && (rl.z & 0xFFu) != 0xFFu, more16 = act && (int)pw1 < 0;
         {
-            // The first 16 compatible predecessors of every row come as a byte list in increasing k (0xFF = none, which
-            // reads the +inf tail of dp); the LDS reads of 8 candidates are issued together.
-            auto list8 = [&](uint32_t la, uint32_t lb) {
-                int kk[8]; double dd[8]; uint32_t ff[8];
+            auto list8 = [&](uint32_t la, uint32_t lb, uint32_t pw) {
+                uint32_t ad[8]; double dd[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    kk[j] = (int)(((j < 4 ? la : lb) >> (8 * (j & 3))) & 0xFFu);
-                    dd[j] = dp[kk[j]]; ff[j] = fp[kk[j]];
+                    ad[j] = (((j < 4 ? la : lb) >> (8 * (j & 3))) & 0xFFu) << 3;
+                    dd[j] = *reinterpret_cast<const double *>(prev + ad[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const double c = __dadd_rn(dd[j], (double)flow_l1_biased(Fc, ff[j]));
+                    const double c = __dadd_rn(dd[j], (double)((pw >> (4 * j)) & 7u));
                     const bool t = c < bestv;               // +inf + psi = +inf never wins
-                    bestv = t ? c : bestv; bestk = t ? kk[j] : bestk;
+                    bestv = __builtin_fmin(bestv, c); besta = t ? ad[j] : besta;
                 }
             };
-            list8(act ? rl.x : 0xFFFFFFFFu, act ? rl.y : 0xFFFFFFFFu);
-            if (__ballot(cnt > 8)) list8(act ? rl.z : 0xFFFFFFFFu, act ? rl.w : 0xFFFFFFFFu);
-            if (__ballot(cnt > BCD_LIST)) {
+            list8(rl.x, rl.y, pw0);
+            PROF(2)
+            if (__ballot(more8)) list8(rl.z, rl.w, pw1);
+            PROF(3)
+            if (__ballot(more16)) {
                 // some rows are denser still: those lanes fetch their 160-bit row and walk what is left behind the 16th
                 // list entry, four set bits per round; still increasing k, so strict '<' stands
-                const bool more = cnt > BCD_LIST;
                 const int k15 = (int)(rl.w >> 24);
+                const size_t rowidx = ((size_t)(pix0 + i * pstep) * 2 + dir) * LP + tl;
                 const uint32_t *mrow = a.masks + rowidx * BCD_MASK_WORDS;
                 unsigned long long w0 = 0, w1 = 0, w2 = 0;
-                if (more) {
+                if (more16) {
                     w0 = (unsigned long long)mrow[0] | ((unsigned long long)mrow[1] << 32);
                     w1 = (unsigned long long)mrow[2] | ((unsigned long long)mrow[3] << 32);
                     w2 = (unsigned long long)mrow[4];
@@ -362,56 +442,64 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
                     return k;
                 };
                 while (w0 | w1 | w2) {
-                    bool v0, v1, v2, v3;
-                    const int k0 = next_bit(v0), k1 = next_bit(v1), k2 = next_bit(v2), k3 = next_bit(v3);
-                    const double d0 = dp[k0], d1 = dp[k1], d2 = dp[k2], d3 = dp[k3];     // invalid slots read label 0: harmless
-                    const uint32_t f0 = fp[k0], f1 = fp[k1], f2 = fp[k2], f3 = fp[k3];
-                    const double c0 = __dadd_rn(d0, (double)flow_l1_biased(Fc, f0));
-                    const double c1 = __dadd_rn(d1, (double)flow_l1_biased(Fc, f1));
-                    const double c2 = __dadd_rn(d2, (double)flow_l1_biased(Fc, f2));
-                    const double c3 = __dadd_rn(d3, (double)flow_l1_biased(Fc, f3));
-                    bool t;
-                    t = v0 && c0 < bestv; bestv = t ? c0 : bestv; bestk = t ? k0 : bestk;
-                    t = v1 && c1 < bestv; bestv = t ? c1 : bestv; bestk = t ? k1 : bestk;
-                    t = v2 && c2 < bestv; bestv = t ? c2 : bestv; bestk = t ? k2 : bestk;
-                    t = v3 && c3 < bestv; bestv = t ? c3 : bestv; bestk = t ? k3 : bestk;
+                    bool v[4]; int kk[4]; double dd[4]; uint32_t ff[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) kk[j] = next_bit(v[j]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { dd[j] = *reinterpret_cast<const double *>(prev + 8 * kk[j]); ff[j] = fprev[kk[j]]; }   // invalid slots read label 0: harmless
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const double c = __dadd_rn(dd[j], (double)flow_l1_biased(Fc, ff[j]));
+                        const bool t = v[j] && c < bestv;
+                        bestv = t ? c : bestv; besta = t ? (uint32_t)kk[j] << 3 : besta;
+                    }
                 }
             }
         }
+        PROF(4)
         unsigned long long key = ~0ull;
         if (act) {
-            const bool found = bestk != 0x7fffffff;
+            const bool found = besta != 0x7fffffffu;
             const double mincost = found ? bestv : perm.v;
-            const int pl = found ? bestk : perm.k;
+            const int pl = found ? (int)(besta >> 3) : perm.k;
             const double dpc = __dadd_rn(mincost, small);
-            dpbuf[cur * BCD_LDS_LABELS + tl] = dpc;
-            fpbuf[cur * BCD_LDS_LABELS + tl] = Fc;
-            back[(size_t)i * LP + tl] = (uint8_t)pl;
+            s_dp[CUR * BCD_LDS_LABELS + tl] = dpc;
+            s_fp[CUR * BCD_LDS_LABELS + tl] = Fc;
+            backp[(size_t)i * LP] = (uint8_t)pl;
             key = (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, dpc));
         }
+        PROF(5)
         {
             int fl;
-            const unsigned long long m = wave_key_min(key, &fl);
-            if (lane == 0) { permv[cur * 4 + wave] = m; permi[cur * 4 + wave] = wave * 64 + fl; }
+            const unsigned long long m = wave_key_min_asm(key, &fl);
+            if (lane == 0) { permv[CUR * 4 + wave] = m; permi[CUR * 4 + wave] = wave * 64 + fl; }
         }
+        PROF(6)
         // LDS-only barrier: __syncthreads() would also wait for the global prefetches issued in this step (vmcnt(0)) and
         // put their full latency on every step of the chain
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        PROF(7)
         pn = tn;
-        cur ^= 1;
     };
-    for (int i = 1; i < len; i += 3) {
-        step(i, A);
-        if (i + 1 < len) step(i + 1, B);
-        if (i + 2 < len) step(i + 2, C);
+    for (int i = 1; i < len; i += 6) {
+        step(IntC<1>(), i, A);
+        if (i + 1 < len) step(IntC<0>(), i + 1, B);
+        if (i + 2 < len) step(IntC<1>(), i + 2, C);
+        if (i + 3 < len) step(IntC<0>(), i + 3, A);
+        if (i + 4 < len) step(IntC<1>(), i + 4, B);
+        if (i + 5 < len) step(IntC<0>(), i + 5, C);
     }
+#ifdef BCD_PROF
+    if (blockIdx.x == 7 && lane == 0) for (int k = 0; k < 8; k++) g_bcd_prof[wave][k] += pacc[k];
+#endif
+    const int cur = (len & 1) ? 1 : 0;         // the buffer the step after the last one would write; the last written is cur^1
 
     // ---- end label: first minimum of dp[len-1] (python bcd.py:231-237): tpsi + dp is monotone in dp, but two different
     // dp may round to the same sum, so the minimum is taken over dp itself
     if (tid < 64) {
-        const double *dp = dpbuf + (cur ^ 1) * BCD_LDS_LABELS;
+        const double *dp = s_dp + (cur ^ 1) * BCD_LDS_LABELS;
         Cand m; m.v = 800000.0; m.k = 0x7fffffff;
         for (int k = lane; k < pn; k += 64) { double c = dp[k]; if (c < m.v) { m.v = c; m.k = k; } }
         wave_min_lane0(m);
@@ -419,6 +507,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     }
     __syncthreads();
     // ---- traceback (python bcd.py:239-253): chunks of back-pointer rows are staged in LDS, one thread walks them
+    uint8_t *back = a.back + (size_t)chain * len * LP;
     int pl = *s_label;
     if (tid == 0) a.bestlabels[pix0 + (len - 1) * pstep] = pl;
     for (int hi = len - 1; hi >= 1; hi -= BCD_TB_STEPS) {
@@ -472,29 +561,29 @@ static size_t rec_bytes(const dflow_params *p)
 
 size_t bcd_ws_bytes(const dflow_params *p) { return back_bytes(p) + mask_bytes(p) + rec_bytes(p); }
 
-int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, void *ws, hipStream_t s)
+int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop, void *ws,
+                       hipStream_t s)
 {
     uint32_t *masks = (uint32_t *)((char *)ws + back_bytes(p));
     uint32_t *recs = (uint32_t *)((char *)ws + back_bytes(p) + mask_bytes(p));
     long long items = 2LL * p->pich * p->picw;
     hipLaunchKernelGGL(bcd_masks_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p->pich, p->picw, p->label_pitch,
-                       p->tpsi, proposals, nprop, masks, recs);
+                       p->tpsi, proposals, lcosts, nprop, masks, recs);
     return dflow_check_launch("bcd_masks_kernel");
 }
 
-int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop,
-                     int32_t *bestlabels, int phase, void *ws, hipStream_t s)
+int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, int32_t *bestlabels, int phase,
+                     void *ws, hipStream_t s)
 {
     int nchains, len;
     phase_dims(p, phase, nchains, len);
     if (nchains == 0) return DFLOW_OK;
     BcdArgs a;
     a.H = p->pich; a.W = p->picw; a.LP = p->label_pitch; a.tpsi = p->tpsi; a.phase = phase; a.lamda = p->lamda;
-    a.proposals = proposals; a.lcosts = lcosts; a.nprop = nprop; a.bestlabels = bestlabels;
+    a.proposals = proposals; a.nprop = nprop; a.bestlabels = bestlabels;
     a.back = (uint8_t *)ws; a.masks = (const uint32_t *)((char *)ws + back_bytes(p));
     a.recs = (const uint32_t *)((char *)ws + back_bytes(p) + mask_bytes(p));
-    size_t shmem = 2 * 256 * (sizeof(double) + sizeof(uint32_t)) + 2 * 4 * (sizeof(double) + sizeof(int)) + 16 +
-                   (size_t)BCD_TB_STEPS * p->label_pitch + (size_t)len * (sizeof(uint32_t) + sizeof(int));
+    size_t shmem = (size_t)(len + 2) * sizeof(uint32_t) + (size_t)len * sizeof(int);
     hipLaunchKernelGGL(bcd_chain_kernel, dim3(nchains), dim3(BCD_THREADS), shmem, s, a);
     return dflow_check_launch("bcd_chain_kernel");
 }

@@ -96,10 +96,11 @@ size_t knn_mfma_ws_bytes(const dflow_params *p);
 bool knn_mfma_supported(const dflow_params *p);
 int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
                      int32_t *nprop, const int32_t *bestlabels, hipStream_t s);
-int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop,
-                     int32_t *bestlabels, int phase, void *ws, hipStream_t s);
+int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, int32_t *bestlabels, int phase,
+                     void *ws, hipStream_t s);
 size_t bcd_ws_bytes(const dflow_params *p);
-int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, void *ws, hipStream_t s);
+int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop, void *ws,
+                       hipStream_t s);
 int launch_labels_to_flow(const dflow_params *p, const uint32_t *proposals, const int32_t *bestlabels, float *flow,
                           hipStream_t s);
 int launch_fb_consistency(const dflow_params *p, const float *fwd, const float *bwd, float tresh, float *sparse,

@@ -107,27 +107,27 @@ class DiscreteFlow:
 
     def pakovanje(self):
         """daisy i flann.py:256-309: compat bit matrices, built into the workspace for the chain kernel."""
-        _lib.check(_lib.lib().dflow_bcd_prepare(self._pp(), self.proposals.data_ptr(), self.nprop.data_ptr(),
-                                                self.ws.data_ptr(), self.ws_bytes, self._stream()), "dflow_bcd_prepare")
+        _lib.check(_lib.lib().dflow_bcd_prepare(self._pp(), self.proposals.data_ptr(), self.lcosts.data_ptr(),
+                                                self.nprop.data_ptr(), self.ws.data_ptr(), self.ws_bytes, self._stream()),
+                   "dflow_bcd_prepare")
         self._bcd_ready = True
 
     def bcd_phase(self, phase):
         """One of the four chain loops of ceoBCD, python bcd.py:265-277."""
         if not self._bcd_ready:
             self.pakovanje()
-        _lib.check(_lib.lib().dflow_bcd_phase(self._pp(), self.proposals.data_ptr(), self.lcosts.data_ptr(),
-                                              self.nprop.data_ptr(), self.bestlabels.data_ptr(), phase,
-                                              self.ws.data_ptr(), self.ws_bytes, self._stream()), "dflow_bcd_phase")
+        _lib.check(_lib.lib().dflow_bcd_phase(self._pp(), self.proposals.data_ptr(), self.nprop.data_ptr(),
+                                              self.bestlabels.data_ptr(), phase, self.ws.data_ptr(), self.ws_bytes,
+                                              self._stream()), "dflow_bcd_phase")
 
     def ceoBCD(self, bcd_times, on_sweep=None):
         """python bcd.py:261-284.  on_sweep(w) is called after sweep w (the reference saves .npy there)."""
         if not self._bcd_ready:
             self.pakovanje()
         for w in range(1, bcd_times + 1):
-            _lib.check(_lib.lib().dflow_bcd_sweep(self._pp(), self.proposals.data_ptr(), self.lcosts.data_ptr(),
-                                                  self.nprop.data_ptr(), self.bestlabels.data_ptr(),
-                                                  self.ws.data_ptr(), self.ws_bytes, self._stream()),
-                       "dflow_bcd_sweep")
+            _lib.check(_lib.lib().dflow_bcd_sweep(self._pp(), self.proposals.data_ptr(), self.nprop.data_ptr(),
+                                                  self.bestlabels.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                  self._stream()), "dflow_bcd_sweep")
             if on_sweep is not None:
                 on_sweep(w)
 

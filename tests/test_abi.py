@@ -55,9 +55,9 @@ def test_null_pointers_are_rejected_before_any_launch(L):
     p = L.default_params(64, 64, 8, 8)
     rc = lib.dflow_daisy(C.byref(p), None, None, None, 0, None)
     assert rc == -1 and b"NULL" in lib.dflow_last_error()
-    rc = lib.dflow_bcd_phase(C.byref(p), 1, 1, 1, 1, 7, 1, 1 << 40, None)
+    rc = lib.dflow_bcd_phase(C.byref(p), 1, 1, 1, 7, 1, 1 << 40, None)
     assert rc == -1 and b"phase" in lib.dflow_last_error()
-    rc = lib.dflow_bcd_sweep(C.byref(p), 1, 1, 1, 1, 1, 16, None)
+    rc = lib.dflow_bcd_sweep(C.byref(p), 1, 1, 1, 1, 16, None)
     assert rc == -2 and b"workspace" in lib.dflow_last_error()
 
 
