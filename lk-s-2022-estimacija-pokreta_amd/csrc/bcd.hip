@@ -63,10 +63,12 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
         fcv[j] = k < tn ? flow_bias(proposals[(size_t)pix * LP + k]) : 0u;
         s_cols[wv][k] = fp[j];
     }
-    // lanes = labels of this pixel (three groups of 64), predecessor labels come one by one as wave-uniform scalars:
-    // D = sad + (2^31 - tpsi) has bit 31 set iff the pair is NOT compatible, v_alignbit shifts that bit into the row
-    // word.  Columns run downwards inside each 32-bit word so that column c ends up in bit c.
+    // lanes = labels of this pixel (three groups of 64), predecessor labels come one by one as wave-uniform scalars
+    // (scalar loads of the predecessor's row): D = sad + (2^31 - tpsi) has bit 31 set iff the pair is NOT compatible,
+    // v_alignbit shifts that bit into the row word.  Columns run downwards inside each 32-bit word so that column c ends
+    // up in bit c; columns >= pn (fill values) are forced to "not compatible" afterwards.
     const uint32_t kbias = 0x80000000u - (uint32_t)tpsi;
+    const uint32_t *__restrict__ colp = proposals + (size_t)ppix * LP;
     uint32_t m[3][BCD_MASK_WORDS];
 #pragma unroll
     for (int j = 0; j < BCD_MASK_WORDS; j++) {
@@ -74,12 +76,14 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
         if (32 * j < pn) {
 #pragma unroll
             for (int cc = 31; cc >= 0; cc--) {
-                const int c = 32 * j + cc;
-                const uint32_t col = (uint32_t)__builtin_amdgcn_readlane((int)fp[c >> 6], c & 63);
+                const uint32_t col = flow_bias(colp[32 * j + cc]);
                 m[0][j] = __builtin_amdgcn_alignbit(m[0][j], __builtin_amdgcn_sad_u16(col, fcv[0], kbias), 31);
                 m[1][j] = __builtin_amdgcn_alignbit(m[1][j], __builtin_amdgcn_sad_u16(col, fcv[1], kbias), 31);
                 m[2][j] = __builtin_amdgcn_alignbit(m[2][j], __builtin_amdgcn_sad_u16(col, fcv[2], kbias), 31);
             }
+            const int nv = pn - 32 * j;                      // valid columns in this word (wave-uniform)
+            const uint32_t inval = nv >= 32 ? 0u : ~0u << nv;
+            m[0][j] |= inval; m[1][j] |= inval; m[2][j] |= inval;
         }
     }
     const size_t rowbase = ((size_t)pix * 2 + dir) * (size_t)LP;
@@ -252,9 +256,17 @@ __device__ static inline unsigned long long wave_key_min_asm(unsigned long long 
 {
     const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
     const uint32_t mh = wave_u32_min_asm(hi);
-    const uint32_t ml = wave_u32_min_asm(hi == mh ? lo : 0xFFFFFFFFu);
-    const unsigned long long hit = __ballot(hi == mh && lo == ml);
-    *first_lane = __ffsll((long long)hit) - 1;
+    const unsigned long long tie = __ballot(hi == mh);
+    uint32_t ml; int fl;
+    if (__popcll(tie) == 1) {
+        // one lane alone has the smallest high word (the usual case): it is the minimum
+        fl = __ffsll((long long)tie) - 1;
+        ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, fl);
+    } else {
+        ml = wave_u32_min_asm(hi == mh ? lo : 0xFFFFFFFFu);
+        fl = __ffsll((long long)__ballot(hi == mh && lo == ml)) - 1;
+    }
+    *first_lane = fl;
     return ((unsigned long long)mh << 32) | ml;
 }
 
@@ -398,25 +410,31 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         // issued together.  Candidates are tracked by their dp offset 8 k.
         PROF(1)
         double bestv = 1e300; uint32_t besta = 0x7fffffffu;
-        const bool more8 = act && (rl.z & 0xFFu) != 0xFFu, more16 = act && (int)pw1 < 0;
+        const bool more8 = act && (rl.z & 0xFFu) != 0xFFu, more12 = act && (rl.w & 0xFFu) != 0xFFu, more16 = act && (int)pw1 < 0;
         {
-            auto list8 = [&](uint32_t la, uint32_t lb, uint32_t pw) {
-                uint32_t ad[8]; double dd[8];
+            // NL candidates from the list words la (entries 0..3 of this call) and lb (4..7), pair costs from nibble `nib0` on
+            auto listn = [&](auto nlc, uint32_t la, uint32_t lb, uint32_t pw, const int nib0) {
+                constexpr int NL = decltype(nlc)::value;
+                uint32_t ad[NL]; double dd[NL];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < NL; j++) {
                     ad[j] = (((j < 4 ? la : lb) >> (8 * (j & 3))) & 0xFFu) << 3;
                     dd[j] = *reinterpret_cast<const double *>(prev + ad[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const double c = __dadd_rn(dd[j], (double)((pw >> (4 * j)) & 7u));
+                for (int j = 0; j < NL; j++) {
+                    const double c = __dadd_rn(dd[j], (double)((pw >> (4 * (nib0 + j))) & 7u));
                     const bool t = c < bestv;               // +inf + psi = +inf never wins
                     bestv = __builtin_fmin(bestv, c); besta = t ? ad[j] : besta;
                 }
             };
-            list8(rl.x, rl.y, pw0);
+            listn(IntC<8>(), rl.x, rl.y, pw0, 0);
             PROF(2)
-            if (__ballot(more8)) list8(rl.z, rl.w, pw1);
+            // most rows have at most 8 members, few more than 12 (wave-uniform branches on the longest row of the wave)
+            if (__ballot(more8)) {
+                listn(IntC<4>(), rl.z, 0u, pw1, 0);
+                if (__ballot(more12)) listn(IntC<4>(), rl.w, 0u, pw1, 4);
+            }
             PROF(3)
             if (__ballot(more16)) {
                 // some rows are denser still: those lanes fetch their 160-bit row and walk what is left behind the 16th
