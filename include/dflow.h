@@ -116,6 +116,17 @@ int dflow_labels_to_flow(const dflow_params *p, const uint32_t *d_proposals, con
 int dflow_fb_consistency(const dflow_params *p, const float *d_fwd, const float *d_bwd, float tresh,
                          float *d_sparse, void *stream);
 
+/* The packedksets file of pakovanje, daisy i flann.py:256-309, for users who feed the reference's own `python bcd.py`:
+ * d_packed (H,W,2,maxnprop*maxnprop/8+1) uint8, slot 0 = pixel vs the pixel below, slot 1 = vs the pixel to the right,
+ * np.packbits bit order.  Every matrix is computed from clean scratch; the reference's bottom-row / right-column loops
+ * (:283-307) reuse theirs, which the host wrapper (compat.py) replays on those H+W matrices. */
+int dflow_pack_compat(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop, uint8_t *d_packed,
+                      void *stream);
+
+/* removeSmallSegments, postprocessing.py:29-76 (unused upstream, :129), on a HOST (dim0,dim1,3) float32 [U,V,valid]
+ * field, in place.  Host code: the reference's region growing depends on its scan order. */
+int dflow_remove_small_segments_host(float *h_sparse, int32_t dim0, int32_t dim1, float tresh, int32_t min_segment_size);
+
 #ifdef __cplusplus
 }
 #endif

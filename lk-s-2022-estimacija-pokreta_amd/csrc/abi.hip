@@ -145,4 +145,19 @@ int dflow_fb_consistency(const dflow_params *p, const float *d_fwd, const float 
     return launch_fb_consistency(p, d_fwd, d_bwd, tresh, d_sparse, (hipStream_t)stream);
 }
 
+int dflow_pack_compat(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop, uint8_t *d_packed,
+                      void *stream)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_proposals); CHECK_PTR(d_nprop); CHECK_PTR(d_packed);
+    return launch_pack_compat(p, d_proposals, d_nprop, d_packed, (hipStream_t)stream);
+}
+
+int dflow_remove_small_segments_host(float *h_sparse, int32_t dim0, int32_t dim1, float tresh, int32_t min_segment_size)
+{
+    if (!h_sparse) return dflow_set_error(DFLOW_EINVAL, "h_sparse is NULL");
+    if (dim0 <= 0 || dim1 <= 0) return dflow_set_error(DFLOW_EINVAL, "field size %dx%d", dim0, dim1);
+    return host_remove_small_segments(h_sparse, dim0, dim1, tresh, min_segment_size);
+}
+
 }  // extern "C"

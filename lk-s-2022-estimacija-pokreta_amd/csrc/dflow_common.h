@@ -103,5 +103,7 @@ int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const f
                        hipStream_t s);
 int launch_labels_to_flow(const dflow_params *p, const uint32_t *proposals, const int32_t *bestlabels, float *flow,
                           hipStream_t s);
+int launch_pack_compat(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, uint8_t *packed, hipStream_t s);
+int host_remove_small_segments(float *flow, int A, int B, float tresh, int min_segment_size);
 int launch_fb_consistency(const dflow_params *p, const float *fwd, const float *bwd, float tresh, float *sparse,
                           hipStream_t s);

@@ -6,7 +6,8 @@
 Same positional arguments, same image naming (../data_scene_flow/training/image_2/0001{idx}_1{0|1}.png), same
 output files in the current directory: the WTA flow/labels "posle 00", proposals_nakon_gausa,
 lcosts_nakon_gausa, nprop -- in the reference's dtypes -- plus a Middlebury .flo next to every flow .npy.
-The compat bit matrices (packedksets, 2.6 GB) are NOT written: the GPU BCD evaluates the predicate on the fly.
+The compat bit matrices (packedksets, 2.6 GB; with dopython=0 the four 'pakovani za c' copies) are written only with
+--packedksets, for users of the reference's own BCD scripts: the GPU BCD builds its own compact lists in HBM.
 All computation runs in libdflow.so on the GPU; there is no CPU fallback.
 
 Options for inputs the reference cannot handle: --image1/--image2 PATH, --cell HxW, --synthetic HxW
@@ -33,6 +34,7 @@ def main(argv=None):
     ap.add_argument("picindex"); ap.add_argument("backward", choices=("0", "1")); ap.add_argument("dopython", choices=("0", "1"))
     ap.add_argument("--image1"); ap.add_argument("--image2"); ap.add_argument("--cell"); ap.add_argument("--synthetic")
     ap.add_argument("--seed", type=int, default=0); ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--packedksets", action="store_true", help="also write the reference's compat-matrix file(s)")
     a = ap.parse_args(argv)
     pipeline = importlib.import_module(PKG + ".pipeline")
     flowio = importlib.import_module(PKG + ".flowio")
@@ -65,6 +67,14 @@ def main(argv=None):
     np.save(flowio.stage_name(idx, a.backward, "proposals_nakon_gausa"), st["proposals"])   # sacuvajPodatke1 :249-253
     np.save(flowio.stage_name(idx, a.backward, "lcosts_nakon_gausa"), st["lcosts"])
     np.save(flowio.stage_name(idx, a.backward, "nprop"), st["nprop"])
+    if a.packedksets:                                                       # pakovanje :308 / pakovanjeZaC :394-397
+        compat = importlib.import_module(PKG + ".compat")
+        pk = compat.packedksets(df)
+        if a.dopython == "1":
+            np.save(flowio.stage_name(idx, a.backward, "packedksets"), pk)
+        else:
+            for k, arr in enumerate(compat.pakovani_za_c(pk)):
+                np.save(flowio.stage_name(idx, a.backward, "pakovani za c %d" % k), arr)
     print("daisy i flann: %dx%d, cells %dx%d, nprop %d..%d" % (picw, pich, cellw, cellh, st["nprop"].min(), st["nprop"].max()))
 
 

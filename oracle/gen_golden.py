@@ -93,8 +93,8 @@ class NormalReplayer:
         return loc + off + 0.5
 
 
-def run_reference_pass(p, img_first, img_second, idx, backward, bcd_times, workdir):
-    """Executes `daisy i flann.py idx backward 1` then `python bcd.py idx backward bcd_times` in workdir."""
+def run_reference_pass(p, img_first, img_second, idx, backward, bcd_times, workdir, dopython=1):
+    """Executes `daisy i flann.py idx backward dopython` then (dopython=1) `python bcd.py idx backward bcd_times` in workdir."""
     H, W = p.pich, p.picw
     images = {f"_1{backward}.png": img_first, f"_1{1 - backward}.png": img_second}
 
@@ -127,14 +127,15 @@ def run_reference_pass(p, img_first, img_second, idx, backward, bcd_times, workd
     os.chdir(workdir)
     try:
         with contextlib.redirect_stdout(io.StringIO()):
-            sys.argv = ["daisy i flann.py", str(idx), str(backward), "1"]
+            sys.argv = ["daisy i flann.py", str(idx), str(backward), str(dopython)]
             exec(compile(patched_source("daisy i flann.py", H, W, p.cellh, p.cellw), "daisy i flann.py", "exec"),
                  {"__name__": "__main__"})
             np.random.normal = saved_normal
-            sys.modules["cv2"], sys.modules["pyflann"] = types.ModuleType("cv2"), types.ModuleType("pyflann")
-            sys.argv = ["python bcd.py", str(idx), str(backward), str(bcd_times)]
-            exec(compile(patched_source("python bcd.py", H, W, p.cellh, p.cellw), "python bcd.py", "exec"),
-                 {"__name__": "__main__"})
+            if dopython:
+                sys.modules["cv2"], sys.modules["pyflann"] = types.ModuleType("cv2"), types.ModuleType("pyflann")
+                sys.argv = ["python bcd.py", str(idx), str(backward), str(bcd_times)]
+                exec(compile(patched_source("python bcd.py", H, W, p.cellh, p.cellw), "python bcd.py", "exec"),
+                     {"__name__": "__main__"})
     finally:
         np.random.normal, sys.argv = saved_normal, saved_argv
         os.chdir(saved_cwd)
@@ -145,6 +146,9 @@ def run_reference_pass(p, img_first, img_second, idx, backward, bcd_times, workd
                 sys.modules[k] = v
     P = "1%02d" % idx
     ld = lambda n: np.load(os.path.join(workdir, n))
+    if not dopython:       # pakovanjeZaC instead of pakovanje; no BCD run (python bcd.py needs packedksets)
+        return dict(nprop=ld(f"Daisy output slike {P} backward={backward} nprop.npy"),
+                    za_c=[ld(f"Daisy output slike {P} backward={backward} pakovani za c {k}.npy") for k in range(4)])
     out = dict(
         proposals=ld(f"Daisy output slike {P} backward={backward} proposals_nakon_gausa.npy"),
         lcosts=ld(f"Daisy output slike {P} backward={backward} lcosts_nakon_gausa.npy"),

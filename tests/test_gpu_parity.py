@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C-ABI) with the CPU oracle and with the reference's golden vectors.
 Everything here needs a real MI355X: run with `pytest -m gpu`."""
+import hashlib
+
 import numpy as np
 import pytest
 
@@ -90,6 +92,14 @@ def test_hip_path_matches_reference_golden(torch_, golden, name, backward):
     assert np.array_equal(st["nprop"], g[k + "nprop"])
     assert np.array_equal(st["proposals"][:2], g[k + "proposals_rows"])
     assert np.array_equal(st["lcosts"][:2], g[k + "lcosts_rows"])
+    # the reference's packedksets file (pakovanje): GPU bit matrices + host replay of its border scratch reuse
+    pk = pkg("compat").packedksets(df)
+    assert np.array_equal(pk[1, 1], g[k + "packedksets_px"])
+    assert hashlib.sha256(pk.tobytes()).hexdigest() == str(g[k + "packedksets_sha"])
+    if name == "a40x48_c5x6" and backward == 0:         # pakovanjeZaC (dopython=0) of the same pass
+        ge = golden("extras")
+        for j, arr in enumerate(pkg("compat").pakovani_za_c(pk)):
+            assert hashlib.sha256(arr.tobytes()).hexdigest() == str(ge["za_c%d_sha" % j])
     for w in range(1, int(g["bcd_times"]) + 1):
         df.ceoBCD(1)
         assert np.array_equal(df.bestlabels.cpu().numpy(), g[k + "labels%02d" % w]), "sweep %d" % w
@@ -260,7 +270,7 @@ def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
     O = oracle
     H, W, ch, cw = 48, 64, 8, 8
     monkeypatch.chdir(tmp_path)
-    monkeypatch.setattr(sys, "argv", ["daisy i flann.py", "6", "0", "1", "--synthetic", "%dx%d" % (H, W), "--cell", "%dx%d" % (ch, cw), "--seed", "11"])
+    monkeypatch.setattr(sys, "argv", ["daisy i flann.py", "6", "0", "1", "--synthetic", "%dx%d" % (H, W), "--cell", "%dx%d" % (ch, cw), "--seed", "11", "--packedksets"])
     runpy.run_path(os.path.join(ROOT, PKG, "daisy i flann.py"), run_name="__main__")
     monkeypatch.setattr(sys, "argv", ["python bcd.py", "6", "0", "2", "--cell", "%dx%d" % (ch, cw)])
     runpy.run_path(os.path.join(ROOT, PKG, "python bcd.py"), run_name="__main__")
@@ -271,6 +281,8 @@ def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
     lc = np.load("Daisy output slike 106 backward=0 lcosts_nakon_gausa.npy")
     assert lc.dtype == np.float64 and np.array_equal(lc, ref["lcosts"])
     assert np.array_equal(np.load("Daisy output slike 106 backward=0 nprop.npy"), ref["nprop"])
+    pk = np.load("Daisy output slike 106 backward=0 packedksets.npy")
+    assert pk.dtype == np.uint8 and np.array_equal(pk, O.pack_compat(O.make_params(H, W, ch, cw, seed=11), ref["proposals"], ref["nprop"]))
     for w in range(3):
         f = np.load("Gotova flow slika 106 backward=0 posle %02d BCD.npy" % w)
         assert f.dtype == np.float64 and np.array_equal(f, ref["flows"][w])
