@@ -42,14 +42,14 @@ def cpu_baseline(synth):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     O.build()
-    h, w = 109, 256                                  # 1/16 of the frame area, same 27x64 cells, same bcd_times
+    h, w = 109, 512                                  # 1/8 of the frame area, same 27x64 cells, same bcd_times
     img1, img2, _ = synth.make_pair(h, w, seed=4242, amp_x=40.0, amp_y=20.0)
     p = O.make_params(h, w, 27, 64, seed=1)
     t0 = time.perf_counter()
     O.full_pass(p, img1, img2, BCD_TIMES)
     dt = time.perf_counter() - t0
     return {"value": h * w / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d crop-sized synthetic pair (1/16 frame), cells 27x64, bcd_times=%d, %.1f s; "
+            "sample": "%dx%d crop-sized synthetic pair (1/8 frame), cells 27x64, bcd_times=%d, %.1f s; "
                       "C restatement of daisy i flann.py + python bcd.py (oracle/), exact kNN instead of FLANN"
                       % (w, h, BCD_TIMES, dt)}
 
@@ -208,10 +208,11 @@ def main():
                                       "flow fields gathered on rank 0" % P},
             "roofline": {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         # FETCH_SIZE + WRITE_SIZE per launch, rocprofv3 --pmc (one counter per pass, raw values,
-                         # profiles/r01_pmc_traffic.txt; gfx950 FETCH_SIZE reports about half of wide reads); expected from the
-                         # access pattern: 1.14 GB (160 label slots x (8 B label + 24 B compat record) per visited pixel)
-                         "traffic": (597257 + 33598) * 1024,
+                         # HBM-side bytes per launch from rocprofv3 --pmc (one counter per pass, profiles/r01_pmc_traffic.txt):
+                         # FETCH_SIZE 598080 KB, doubled as MI355X_MICROARCH.md prescribes for gfx950's wide (16 B/lane) reads,
+                         # + WRITE_SIZE 33645 KB.  Expected from the access pattern: 1.14 GB of 32-byte label records (160 rows
+                         # per visited pixel: the compat lists the reference keeps in packedksets ride along) + 36 MB back-pointers
+                         "traffic": (2 * 598080 + 33645) * 1024,
                          "launch_ms": bcd_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "serial Viterbi chains (218-512 workgroups x 436-1024 dependent steps): latency-bound, "
                                  "not bandwidth-bound; launch_ms is measured with %d pairs in flight" % P},

@@ -42,3 +42,27 @@ def error_metrics(test_uvv, gt_uvv, abs_thresh=3.0):
     mean_epe = float(np.average(err)) if n else float("nan")
     outliers = float((err > abs_thresh).sum() * 100 / n) if n else float("nan")
     return mean_epe, outliers, n
+
+
+def ucitajFlow(path):
+    """FlowImage.ucitajFlow, visualization.py:97-124: a flow file -> (H,W,3) float32 [U,V,valid].  '.png' = KITTI ground
+    truth (16-bit, :37-53), '.npy' = the hot path's [dy,dx] fields or a [U,V,valid]-like 3-channel field read with the same
+    channel swap the reference applies (:104-110), '.flo' = Middlebury [u,v] (:118-124)."""
+    import os
+    from . import flowio
+    ext = os.path.splitext(path)[1]
+    if ext == ".png":
+        return flowio.read_kitti_flow_png(path)
+    if ext == ".npy":
+        flow = np.load(path)
+        out = np.zeros(flow.shape[:2] + (3,), np.float32)
+        out[..., 0] = flow[..., 1]
+        out[..., 1] = flow[..., 0]
+        out[..., 2] = (flow[..., 2] != 0) if flow.shape[2] == 3 else 1.0      # setValid(val): "if val" (:55-57)
+        return out
+    if ext == ".flo":
+        uv = flowio.read_flo(path)
+        out = np.ones(uv.shape[:2] + (3,), np.float32)
+        out[..., :2] = uv
+        return out
+    raise ValueError("unsupported flow file: %s" % path)

@@ -100,3 +100,19 @@ def test_pakovani_za_c_and_border_replay_match_reference(oracle, golden):
     for k, arr in enumerate(compat.pakovani_za_c(clean)):
         assert tuple(arr.shape) == tuple(g["za_c%d_shape" % k])
         assert digest(arr, np.uint8) == str(g["za_c%d_sha" % k]), "pakovani za c %d" % k
+
+
+def test_ucitajflow_dispatch(golden, tmp_path):
+    """evaluate.ucitajFlow = FlowImage.ucitajFlow (visualization.py:97-124) for the three file kinds."""
+    g, ev, fio = golden("extras"), pkg("evaluate"), pkg("flowio")
+    png = str(tmp_path / "gt.png")
+    open(png, "wb").write(g["png_bytes"].tobytes())
+    assert np.array_equal(ev.ucitajFlow(png), g["png_field_by_reference"])
+    dydx = np.arange(2 * 3 * 2, dtype=np.float64).reshape(2, 3, 2)
+    np.save(str(tmp_path / "f.npy"), dydx)
+    a = ev.ucitajFlow(str(tmp_path / "f.npy"))
+    assert np.array_equal(a[..., 0], dydx[..., 1]) and np.array_equal(a[..., 1], dydx[..., 0]) and a[..., 2].all()
+    fio.write_flo(str(tmp_path / "f.flo"), dydx)
+    assert np.array_equal(ev.ucitajFlow(str(tmp_path / "f.flo")), a)
+    with pytest.raises(ValueError):
+        ev.ucitajFlow(str(tmp_path / "f.txt"))
