@@ -338,24 +338,27 @@ __device__ static inline void key_insert(unsigned long long (&k)[5], float (&c)[
 }
 
 // one wave per event list; lane = (query column lane&31, candidate half lane>>5), both groups in turn
-__global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve p, int nlists)
+__global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve p)
 {
     const Geom g = a.g;
     const int lane = threadIdx.x & 63, half = lane >> 5;
-    const int lid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (lid >= nlists) return;
+    // Candidate-cell-major order, like the screen kernel: the blocks in flight at any time gather rows of the same few
+    // candidate cells (470 KB each), which then stay in the XCDs' L2.  A block = 4 consecutive 64-query waves of one
+    // (candidate cell, query cell) pair.
     const int win = 2 * g.win + 1;
-    int b = lid;
-    const int wslot = b % (win * win); b /= win * win;
-    const int qwave = b % a.qwaves; const int qcell = b / a.qwaves;
-    const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
+    const int qw4n = (a.qwaves + 3) / 4;
+    int b = blockIdx.x;
+    const int qwave = (b % qw4n) * 4 + (threadIdx.x >> 6); b /= qw4n;
+    const int qslot = b % (win * win); const int ccell = b / (win * win);
+    const int ci = ccell % g.ncx, cj = ccell / g.ncx;
+    const int qci = ci - g.win + qslot / win, qcj = cj - g.win + qslot % win;
+    if (qci < 0 || qci >= g.ncx || qcj < 0 || qcj >= g.ncy) return;
+    const int qcell = qcj * g.ncx + qci;
     const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
-    if (qwave * KM_QPW >= qnpts) return;
-    const int cimin = max(0, qci - g.win), cimax = min(g.ncx - 1, qci + g.win);
-    const int cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
-    const int ncyw = cjmax - cjmin + 1;
-    const int ci = cimin + wslot / ncyw, cj = cjmin + wslot % ncyw;
-    if (ci > cimax) return;
+    if (qwave >= a.qwaves || qwave * KM_QPW >= qnpts) return;
+    const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
+    const int wslot = (ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin);   // reference order: ci outer, cj inner (Q2)
+    const size_t lid = list_id(a, qcell, qwave, wslot);
     const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0;
 
     const int c0 = p.ev_cnt[(size_t)lid * 128 + lane], c1 = p.ev_cnt[(size_t)lid * 128 + 64 + lane];
@@ -573,7 +576,7 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     KmResolve rs;
     rs.d1 = d1; rs.d2 = d2; rs.ev = ev; rs.ev_cnt = ev_cnt; rs.proposals = proposals; rs.lcosts = lcosts;
     rs.ovf_count = ctr; rs.ovf_list = ovf; rs.ovf_cap = KM_OVF_CAP;
-    hipLaunchKernelGGL(knn_resolve_kernel, dim3((unsigned)((nl + 3) / 4)), dim3(256), 0, s, a, rs, (int)nl);
+    hipLaunchKernelGGL(knn_resolve_kernel, dim3((unsigned)(g.ncx * g.ncy * win * win * ((a.qwaves + 3) / 4))), dim3(256), 0, s, a, rs);
     rc = dflow_check_launch("knn_resolve_kernel");
     if (rc) return rc;
     rc = launch_knn_fix(p, d1, d2, proposals, lcosts, ctr, ovf, KM_OVF_CAP, ctr + 1, s);

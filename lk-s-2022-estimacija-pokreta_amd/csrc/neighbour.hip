@@ -62,9 +62,12 @@ __device__ static inline bool tv_in(const uint32_t *prow, int lo, int hi, uint32
     return false;
 }
 
-__global__ void __launch_bounds__(128) neighbour_kernel(NbrArgs a)
+#define NBR_THREADS 128
+
+__global__ void __launch_bounds__(NBR_THREADS) neighbour_kernel(NbrArgs a)
 {
     __shared__ uint32_t thr[128];
+    extern __shared__ uint32_t s_app[];                      // [ngauss][NBR_THREADS]: the proposals this thread has appended so far
     if (threadIdx.x < 128) thr[threadIdx.x] = a.thr[threadIdx.x];
     __syncthreads();
     const Geom g = a.g;
@@ -75,6 +78,13 @@ __global__ void __launch_bounds__(128) neighbour_kernel(NbrArgs a)
     const int ncellyl = min(g.ncy, g.celly(y) + g.win) - mincellyl;         // :214
     const int mincellxl = max(0, g.cellx(x) - g.win);                       // :215
     uint32_t *prow = a.proposals + (size_t)pix * a.LP;
+    // this pixel's descriptor stays in registers for all of its draws
+    float q[DFLOW_DESC];
+    {
+        const float4 *q4 = reinterpret_cast<const float4 *>(a.d1 + (size_t)pix * DFLOW_DESC);
+#pragma unroll
+        for (int k = 0; k < DFLOW_DESC / 4; k++) { const float4 u = q4[k]; q[4 * k] = u.x; q[4 * k + 1] = u.y; q[4 * k + 2] = u.z; q[4 * k + 3] = u.w; }
+    }
     int np_ = a.nprop[pix], ngp = 0, i = 0;
     for (uint32_t att = 0; i < a.ngauss && att < (uint32_t)a.max_attempts; att++) {
         uint32_t r0, r1;
@@ -89,15 +99,21 @@ __global__ void __launch_bounds__(128) neighbour_kernel(NbrArgs a)
         int lo, hi, lo2, hi2;
         py_slice(broj, broj + a.K, a.L, lo, hi);
         py_slice(np_ - ngp, np_, a.L, lo2, hi2);
-        if (!tv_in(prow, lo, hi, tv) && !tv_in(prow, lo2, hi2, tv)) {       // :226
+        // the second slice is exactly what this thread appended (np_ <= L and ngp <= np_ always): kept in LDS
+        bool dup = tv_in(prow, lo, hi, tv);                                 // :226
+        for (int j = lo2 - (np_ - ngp); !dup && j < hi2 - (np_ - ngp); j++) {
+            const uint32_t v = s_app[j * NBR_THREADS + threadIdx.x];
+            dup = (v & 0xFFFFu) == (tv & 0xFFFFu) || (v >> 16) == (tv >> 16);
+        }
+        if (!dup) {
             prow[np_] = tv;                                                 // :227
-            const float4 *q = reinterpret_cast<const float4 *>(a.d1 + (size_t)pix * DFLOW_DESC);
+            s_app[ngp * NBR_THREADS + threadIdx.x] = tv;
             const float4 *t = reinterpret_cast<const float4 *>(a.d2 + (size_t)tpix * DFLOW_DESC);
             float diff[DFLOW_DESC];
 #pragma unroll
             for (int k = 0; k < DFLOW_DESC / 4; k++) {
-                float4 u = q[k], v = t[k];
-                diff[4 * k] = u.x - v.x; diff[4 * k + 1] = u.y - v.y; diff[4 * k + 2] = u.z - v.z; diff[4 * k + 3] = u.w - v.w;
+                const float4 v = t[k];
+                diff[4 * k] = q[4 * k] - v.x; diff[4 * k + 1] = q[4 * k + 1] - v.y; diff[4 * k + 2] = q[4 * k + 2] - v.z; diff[4 * k + 3] = q[4 * k + 3] - v.w;
             }
             const float s = fabsf(np_pairwise_sum68(diff));                 // :228-229 (Q6)
             a.lcosts[(size_t)pix * a.LP + np_] = s < a.tphi ? s : a.tphi;
@@ -128,6 +144,7 @@ int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, ui
     a.d1 = d1; a.d2 = d2; a.proposals = proposals; a.lcosts = lcosts; a.nprop = nprop; a.bestlabels = bestlabels;
     gauss_thresholds((double)p->sigma, a.thr);
     int n = p->pich * p->picw;
-    hipLaunchKernelGGL(neighbour_kernel, dim3((n + 127) / 128), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(neighbour_kernel, dim3((n + NBR_THREADS - 1) / NBR_THREADS), dim3(NBR_THREADS),
+                       (size_t)(p->ngauss > 0 ? p->ngauss : 1) * NBR_THREADS * sizeof(uint32_t), s, a);
     return dflow_check_launch("neighbour_kernel");
 }
