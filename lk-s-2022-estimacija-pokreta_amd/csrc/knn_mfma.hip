@@ -4,26 +4,28 @@
 // bit for bit -- but the 1.7e10 descriptor pairs of a Sintel pass are screened by f16 MFMA instead of being
 // evaluated one by one:
 //
-//   prep      both images -> rows of 80 f16: 68 scaled descriptor values x~ = f16(64 x) (must be >= 0, as DAISY's
-//             are), then for image 2 two f16 triples h-, h+ of h = 0.5*|64 c|^2 (slightly enlarged / reduced, see
-//             below), for image 1 the matching -1 / 0 selectors, zero padding; and |q~| per query.
-//             With G = q~.c~ (exact products, f32 accumulation) the MFMA value t = G - h equals
-//             tau = 0.5(|64 q|^2 - 64^2 d^2) up to eps(q,c) = 1.25 * 2^-10 * G + 2^-15 h + O(2^-17 |q~|^2): f16
-//             rounding of both operands (relative 2^-11 each, G has only non-negative terms), f32 accumulation,
-//             rounding of h and of the canonical float32 distance.  The bound is per candidate: it is folded into
-//             the MFMA by scaling h (h- = h (1+2^-14)/(1-k), h+ = h (1-2^-14)/(1+k), k = 1.25*2^-10):
-//   screen    (knn_screen_kernel) pass 1: w = G - h- for every (query, candidate) of a (256-query block, candidate
-//             cell); (1-k) w <= tau.  Every lane keeps the 5 largest maxima of its 16-value tile columns -> a5, and
-//             (1-k) a5 is a lower bound of the 5th largest tau of the query.  pass 2: v = G - h+; (1+k) v >= tau.
-//             Only candidates with (1+k) v >= (1-k) a5 - s_q can be among the exact 5 NN: these "events" (a 16-bit
-//             row mask per lane and tile) go to per-lane lists in the workspace.
+//   prep      a fixed centre mu (mean descriptor of a pixel sample, knn_mean_kernel) is subtracted from both images --
+//             distances do not change, the products get smaller -- and both become rows of 80 f16: 68 values
+//             x~ = f16(64 (x - mu)), then for image 2 two f16 triples h-, h+ of h = 0.5*|64 (c - mu)|^2 (enlarged / reduced
+//             by the candidate's share of the error bound, see below), for image 1 the matching -1 / 0 selectors, zero
+//             padding.  With G^ = the MFMA's value of q~.c~ (exact products, f32 accumulation) and E = x~ - 64 (x - mu) the
+//             rounding errors actually made (their norms are computed here, nothing is assumed about f16 rounding),
+//                 |q.c - G^| <= |q~||E_c| + |E_q||c| + eta (|q~||c~| + h)  <=  S_c + S_q,
+//                 S_c = |E_c|^2/(2t) + (t/2)|c|^2 + eta (|c~|^2/2 + h),   S_q = (t/2)|q~|^2 + |E_q|^2/(2t) + (eta/2)|q~|^2
+//             (t = 2^-12.5; eta = 2^-12 bounds the f32 accumulation of the 74 products inside the matrix core, about 25
+//             times what IEEE summation would need), so tau = q.c - h = 0.5(|q|^2 - 64^2 d^2) lies within S_c + S_q of G^ - h.
+//   screen    (knn_screen_kernel) pass 1: w = G^ - h- with h- = h + S_c for every (query, candidate) of a (256-query block,
+//             candidate cell); w - S_q <= tau.  Every lane keeps the 5 largest maxima of its 16-value tile columns -> a5,
+//             and a5 - S_q is a lower bound of the 5th largest tau of the query.  pass 2: v = G^ - h+ with h+ = h - S_c;
+//             v + S_q >= tau.  Only candidates with v >= a5 - 2 S_q - s (s: rounding of the canonical float32 distance)
+//             can be among the exact 5 NN: these "events" (a 16-bit row mask per lane and tile) go to per-lane lists in
+//             the workspace.
 //   resolve   (knn_resolve_kernel) one wave per event list: canonical float32 distance (sequential fmaf chain, with
 //             early exit once the partial sum exceeds the lane's 5th best) and truncated L1 cost (numpy order) of
 //             every event, exact (distance, index) top-5 in registers, proposals [dy,dx] and costs into the cell's
 //             5 slots (Q1-Q3).
-//   fix       lists that overflowed (or a pass with descriptors outside the f16 range / negative values) are redone
-//             by the exact brute-force search (knn.hip).  finalize sets nprop, the WTA label (first minimum, Q4)
-//             and the fills.
+//   fix       lists that overflowed (or a pass with descriptors outside the f16 range / NaN) are redone by the exact
+//             brute-force search (knn.hip).  finalize sets nprop, the WTA label (first minimum, Q4) and the fills.
 //
 // MFMA layout (v_mfma_f32_32x32x16_f16): A = candidates (rows), B = queries (columns): lane l holds
 // A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31]; D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5).
@@ -48,7 +50,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
 #define KM_LIST_WORDS (2 * KM_EVROWS * 64)       // one event list: [group][entry][lane] uint32
 #define KM_EVLIST 64             // candidates per lane and group the resolve kernel lists in LDS
-#define KM_KAPPA 0.001220703125f                 // k = 1.25 * 2^-10
+#define KM_T 1.7263349e-4f                       // t = 2^-12.5: split of the cross terms |q~||E_c|, |E_q||c| (see header)
+#define KM_ETA 2.44140625e-4f                    // eta = 2^-12: allowance for the f32 accumulation inside the matrix core
+#define KM_MEAN_SAMPLES 4096
 
 struct KmGeom {
     Geom g;
@@ -64,15 +68,36 @@ __device__ static inline size_t list_id(const KmGeom &a, int qcell, int qwave, i
 }
 
 // ------------------------------------------------------------------------------------------------ prep
+// mu = mean descriptor over KM_MEAN_SAMPLES evenly spaced pixels of image 2: one block, thread = (dimension, sample group),
+// partial sums combined in a fixed order.  Any mu gives exact results; a good one makes the screen tight.
+__global__ void __launch_bounds__(1024) knn_mean_kernel(const float *__restrict__ d, float *__restrict__ mu, int npix)
+{
+    __shared__ float part[15][DFLOW_DESC];
+    const int k = threadIdx.x % DFLOW_DESC, grp = threadIdx.x / DFLOW_DESC;
+    const int nsamp = npix < KM_MEAN_SAMPLES ? npix : KM_MEAN_SAMPLES, stride = npix / nsamp;
+    if (grp < 15) {
+        float acc = 0.0f;
+        for (int sidx = grp; sidx < nsamp; sidx += 15) acc += d[(size_t)sidx * stride * DFLOW_DESC + k];
+        part[grp][k] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < DFLOW_DESC) {
+        float acc = 0.0f;
+        for (int j = 0; j < 15; j++) acc += part[j][threadIdx.x];
+        const float m = acc / (float)nsamp;
+        mu[threadIdx.x] = (__float_as_uint(m) & 0x7FFFFFFFu) < 0x7F800000u ? m : 0.0f;    // NaN/inf in the sample: centre 0
+    }
+}
+
 // one thread per pixel of one image; which = 0: image 1 (queries), 1: image 2 (candidates)
-__global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restrict__ h, float *__restrict__ nrm,
-                                int *__restrict__ flags, Geom g, int which)
+__global__ void knn_prep_kernel(const float *__restrict__ d, const float *__restrict__ mu, _Float16 *__restrict__ h,
+                                float2 *__restrict__ qs, int *__restrict__ flags, Geom g, int which)
 {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= g.H * g.W) return;
     const float4 *s = reinterpret_cast<const float4 *>(d + (size_t)pix * DFLOW_DESC);
     _Float16 row[KM_K];
-    float ss = 0.0f, sx = 0.0f;
+    float ss = 0.0f, sx = 0.0f, se = 0.0f;
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < DFLOW_DESC / 4; k++) {
@@ -80,26 +105,36 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restric
         float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float sc = KM_ALPHA * e[j];                // exact (power of two)
-            // negative, too large or NaN (tested on the bits: this file is compiled with -fno-honor-nans):
-            // the error bound would not hold
-            bad |= sc < 0.0f || sc >= 60000.0f || (__float_as_uint(sc) & 0x7FFFFFFFu) > 0x7F800000u;
-            _Float16 hv = (_Float16)sc;
+            const float sc = KM_ALPHA * (e[j] - mu[4 * k + j]);   // one rounding (the subtraction); the scaling is exact
+            // too large or NaN (tested on the bits: this file is compiled with -fno-honor-nans): no f16 representation
+            bad |= (__float_as_uint(sc) & 0x7FFFFFFFu) >= 0x476A6000u;      // |sc| >= 60000, inf, NaN
+            const _Float16 hv = (_Float16)sc;
             row[4 * k + j] = hv;
-            float f = (float)hv;
+            const float f = (float)hv, er = f - sc;    // exact: f and sc are within a factor of two of each other, or er = -sc
             ss = ss + f * f;                           // |x~|^2
-            sx = sx + sc * sc;                         // |64 x|^2 from the unrounded values
+            sx = sx + sc * sc;                         // |64 (x - mu)|^2 from the unrounded values
+            se = se + er * er;                         // |x~ - 64 (x - mu)|^2: the rounding error actually made
         }
     }
 #pragma unroll
     for (int k = DFLOW_DESC; k < KM_K; k++) row[k] = (_Float16)0.0f;
+    // Norms with their own float32 rounding (70 operations, relative < 1e-5) and the 2^-24 relative error of the
+    // subtraction (|E| <= sqrt(se) + 2^-24 sqrt(sx)) covered by the factors below.
+    const float ss_u = ss * 1.00002f, sx_u = sx * 1.00002f;
+    const float ee_u = (se + 1.2e-7f * sqrtf(se * sx) + 3.6e-15f * sx) * 1.00002f + 1e-30f;
     if (which == 0) {
         row[68] = (_Float16)-1.0f; row[69] = (_Float16)-1.0f; row[70] = (_Float16)-1.0f;   // pass-1 selectors (h-)
+        // S_q and 0.5 |q|^2 (upper bounds)
+        qs[pix] = make_float2((0.5f * KM_T * ss_u + ee_u * (0.5f / KM_T) + 0.5f * KM_ETA * ss_u) * 1.00001f, 0.5f * sx_u);
     } else {
         const float h = 0.5f * sx;
-        bad |= h >= 50000.0f || (__float_as_uint(h) & 0x7FFFFFFFu) > 0x7F800000u;
-        // h- = h (1+2^-14)/(1-k) rounded up a little, h+ = h (1-2^-14)/(1+k) rounded down a little
-        const float hm = h * 1.0012840f, hp = h * 0.9987190f;
+        // S_c (upper bound) incl. eta h and the float32 rounding of h itself
+        // (the factor also covers eta S_c: the accumulation allowance is on |h +- S_c|, pieces included)
+        const float scs = (ee_u * (0.5f / KM_T) + 0.5f * KM_T * sx_u + KM_ETA * (0.5f * ss_u + h) + 2e-5f * h) * 1.0004f + 1e-6f;
+        bad |= h + scs >= 50000.0f || (__float_as_uint(h + scs) & 0x7FFFFFFFu) > 0x7F800000u;
+        // h- = h + S_c rounded up a little, h+ = h - S_c rounded down a little (the f16 triples carry 33 bits; pieces
+        // below the f16 subnormal range are lost: < 2^-24 absolute each)
+        const float hm = (h + scs) * 1.000001f + 1e-6f, hp = (h - scs) * (h > scs ? 0.999999f : 1.000001f) - 1e-6f;
         float r = hm;
 #pragma unroll
         for (int i = 0; i < 3; i++) { _Float16 pc = (_Float16)r; row[68 + i] = pc; r = r - (float)pc; }
@@ -111,10 +146,9 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restric
     const float4 *r4 = reinterpret_cast<const float4 *>(row);
 #pragma unroll
     for (int k = 0; k < KM_K * 2 / 16; k++) o[k] = r4[k];
-    if (which == 0) nrm[pix] = sqrtf(ss) * 1.0001f;   // a slight over-estimate of |q~|
     if (which == 1 && pix == 0) {
         // sentinel row behind the image (row index H*W): h- = h+ = 60000, everything else 0.  Tile rows beyond the end
-        // of a cell are staged from it: their MFMA value is -60000, below every real one (real h < 50000).
+        // of a cell are staged from it: their MFMA value is -60000, below every real one (real h +- S_c lie inside +-50000).
         _Float16 *sr = h + (size_t)g.H * g.W * KM_K;
         for (int k = 0; k < KM_K; k++) sr[k] = (_Float16)((k == 68 || k == 71) ? 60000.0f : 0.0f);
     }
@@ -124,7 +158,7 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, _Float16 *__restric
 // ------------------------------------------------------------------------------------------------ screen
 struct KmScreen {
     const _Float16 *h1, *h2;       // prepared f16 rows
-    const float *qn;               // |q~| per image-1 pixel
+    const float2 *qs;              // (S_q, 0.5 |q|^2) per image-1 pixel
     uint32_t *ev;                  // [list][2][KM_EVROWS][64]: (tile << 16) | row mask
     uint8_t *ev_cnt;               // [list][2][64]; 255 = overflow
 };
@@ -172,7 +206,7 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 
     // ---- my queries: group gq (0/1), column col; B fragments (last k-step differs between the passes) and slack
     half8 bfrag[2][5], blast2[2];
-    float sq[2];
+    float sq[2], hq[2];
 #pragma unroll
     for (int gq = 0; gq < 2; gq++) {
         int qi = qwave * KM_QPW + gq * 32 + col;
@@ -186,11 +220,12 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         if (half == 0) { b2[4] = (_Float16)0.0f; b2[5] = (_Float16)0.0f; b2[6] = (_Float16)0.0f; b2[7] = (_Float16)-1.0f; }
         else { b2[0] = (_Float16)-1.0f; b2[1] = (_Float16)-1.0f; }
         blast2[gq] = b2;
-        const float qn = p.qn[qpix];
-        sq[gq] = 1.52587890625e-5f * qn * qn + 1e-5f * qn + 1e-6f;       // 2^-16 |q~|^2 + absolute terms
+        const float2 qq = p.qs[qpix];
+        sq[gq] = qq.x; hq[gq] = qq.y;
     }
 
     const int nchunks = (cnpts + KM_CHUNK - 1) / KM_CHUNK;
+    const int ntiles = nchunks * (KM_CHUNK / 32);
     // Asynchronous staging of one chunk straight into LDS (global_load_lds_dwordx4: the LDS address is wave-uniform
     // base + 16*lane, the global address is per lane).  The LDS image is 96 rows of 11 16-byte slots (10 data + 1
     // pad = 176-byte pitch) = 1056 slots = 17 wave-instructions (the last one half used; the buffer is 17 KB).
@@ -200,7 +235,11 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         for (int ins = wave; ins < 17; ins += KM_WAVES) {
             const int slot = ins * 64 + lane;
             int r = slot / 11, part = slot % 11;
-            const int idx = chunk * KM_CHUNK + r;
+            // tile position -> candidate: position p = (tile, row) holds candidate row * ntiles + tile, so that the 16 rows
+            // a lane sees of one tile are far apart in the cell.  Neighbouring pixels have similar descriptors: with raster
+            // order several of a query's 5 best would share a lane's tile column, of which only the maximum enters a5.
+            const int pos = chunk * KM_CHUNK + r;
+            const int idx = (pos & 31) * ntiles + (pos >> 5);
             if (part > 9) part = 0;
             const int cpix = idx < cnpts ? (cy0 + idx / ccw) * g.W + cx0 + idx % ccw : g.H * g.W;   // else: sentinel row
             const char *src = reinterpret_cast<const char *>(p.h2 + (size_t)cpix * KM_K) + part * 16;
@@ -294,7 +333,8 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the over-staged chunks before the buffers are reused
         __builtin_amdgcn_s_barrier();
         if (pass == 0) {
-            // merge the two half-lanes of every query; pass-2 values v qualify iff (1+k) v >= (1-k) a5 - s_q
+            // merge the two half-lanes of every query; pass-2 values v qualify iff v >= a5 - 2 S_q - s, where s covers the
+            // rounding of the canonical float32 distance: relative < 1.1e-5 of 64^2 d^2 / 2 = 0.5|q|^2 - tau <= hq - (a5 - S_q)
 #pragma unroll
             for (int gq = 0; gq < 2; gq++) {
                 float o[5];
@@ -302,7 +342,8 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
                 for (int i = 0; i < 5; i++) o[i] = __shfl_xor(a5[gq][i], 32);
 #pragma unroll
                 for (int i = 0; i < 5; i++) top5_insert_desc(a5[gq], o[i]);
-                const float x = ((1.0f - KM_KAPPA) * a5[gq][4] - sq[gq]) / (1.0f + KM_KAPPA);
+                const float a5v = a5[gq][4];
+                const float x = a5v - 2.0f * sq[gq] - 2.2e-5f * (hq[gq] - a5v + sq[gq]);
                 thr[gq] = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -55000.0f);   // real values are > -50000, sentinel rows -60000
                 bfrag[gq][4] = blast2[gq];                                      // pass 2 selects h+
             }
@@ -360,6 +401,7 @@ __global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve
     const int wslot = (ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin);   // reference order: ci outer, cj inner (Q2)
     const size_t lid = list_id(a, qcell, qwave, wslot);
     const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0;
+    const int ntiles = (ccw * (g.y1(cj) - cy0) + KM_CHUNK - 1) / KM_CHUNK * (KM_CHUNK / 32);   // as in the screen kernel
 
     const int c0 = p.ev_cnt[(size_t)lid * 128 + lane], c1 = p.ev_cnt[(size_t)lid * 128 + 64 + lane];
     if (__ballot(c0 == 255 || c1 == 255)) {          // some lane ran out of list space: exact redo by knn_fix_kernel
@@ -395,12 +437,13 @@ __global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve
         for (int e = 0; e < 8; e++) ent[e] = e < n ? ev[e * 64] : 0u;     // the first 8 entries are fetched together
         int nev = 0;
         auto expand = [&](uint32_t entry) {
-            const int tbase = (int)(entry >> 16) * 32 + 4 * half;
+            const int tile = (int)(entry >> 16);
             uint32_t mask = entry & 0xFFFFu;
             while (mask) {
                 const int r = __ffs(mask) - 1;
                 mask &= mask - 1;
-                if (nev < KM_EVLIST) evl[nev][lane] = (uint16_t)(tbase + (r & 3) + 8 * (r >> 2));
+                // accumulator register r of this lane = tile row 4 half + (r & 3) + 8 (r >> 2) = candidate row * ntiles + tile
+                if (nev < KM_EVLIST) evl[nev][lane] = (uint16_t)((4 * half + (r & 3) + 8 * (r >> 2)) * ntiles + tile);
                 nev++;
             }
         };
@@ -527,7 +570,7 @@ size_t knn_mfma_ws_bytes(const dflow_params *p)
 {
     size_t N = (size_t)p->pich * p->picw;
     size_t nl = num_lists(p);
-    return (2 * N + 1) * KM_K * sizeof(_Float16) + N * sizeof(float) + 512 +
+    return (2 * N + 1) * KM_K * sizeof(_Float16) + N * sizeof(float2) + 1024 +
            KM_OVF_CAP * sizeof(int4) + nl * (KM_LIST_WORDS * sizeof(uint32_t) + 128) + 1024;
 }
 
@@ -549,9 +592,10 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     char *w = (char *)ws;
     _Float16 *h1 = (_Float16 *)w; w += N * KM_K * sizeof(_Float16);
     _Float16 *h2 = (_Float16 *)w; w += (N + 1) * KM_K * sizeof(_Float16);   // + sentinel row
-    float *qn = (float *)w; w += N * sizeof(float);
+    float2 *qs = (float2 *)w; w += N * sizeof(float2);
     w = align256(w);
     int *ctr = (int *)w; w += 256;              // ctr[0] = overflow count, ctr[1] = flags
+    float *mu = (float *)w; w += 512;           // centre of the screen's coordinates
     int4 *ovf = (int4 *)w; w += KM_OVF_CAP * sizeof(int4);
     w = align256(w);
     uint32_t *ev = (uint32_t *)w; w += nl * KM_LIST_WORDS * sizeof(uint32_t);
@@ -559,8 +603,9 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     if (hipMemsetAsync(ctr, 0, 256, s) != hipSuccess)
         return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_knn_mfma");
     int nb = (int)((N + 255) / 256);
-    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, h1, qn, ctr + 1, g, 0);
-    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d2, h2, (float *)nullptr, ctr + 1, g, 1);
+    hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(1024), 0, s, d2, mu, (int)N);
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, (const float *)mu, h1, qs, ctr + 1, g, 0);
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d2, (const float *)mu, h2, (float2 *)nullptr, ctr + 1, g, 1);
 
     KmGeom a;
     a.g = g; a.LP = p->label_pitch; a.tphi = p->tphi;
@@ -568,7 +613,7 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     int win = 2 * g.win + 1;
     int qchunks = (a.qwaves + KM_WAVES - 1) / KM_WAVES;
     KmScreen sc;
-    sc.h1 = h1; sc.h2 = h2; sc.qn = qn; sc.ev = ev; sc.ev_cnt = ev_cnt;
+    sc.h1 = h1; sc.h2 = h2; sc.qs = qs; sc.ev = ev; sc.ev_cnt = ev_cnt;
     size_t shmem = (size_t)KM_NBUF * KM_ABUF;
     hipLaunchKernelGGL(knn_screen_kernel, dim3(g.ncx * g.ncy * qchunks * win * win), dim3(KM_THREADS), shmem, s, a, sc);
     int rc = dflow_check_launch("knn_screen_kernel");

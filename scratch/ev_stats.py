@@ -8,11 +8,11 @@ df = pl.DiscreteFlow(H,W,seed=99)
 df.load_pair(img1,img2); df.generisi(); torch.cuda.synchronize()
 N=H*W
 def al(x): return (x+255)//256*256
-off = (2*N+1)*160 + N*4
+off = (2*N+1)*160 + N*8
 base = df.ws.data_ptr()
 off = al(base+off)-base
 ctr = df.ws[off:off+8].cpu().numpy().view(np.int32); print('ovf count, flags', ctr)
-off += 256 + 8192*16
+off += 256 + 512 + 8192*16
 off = al(base+off)-base
 ncx,ncy=16,16; qwaves=(64*31+63)//64; nl = ncx*ncy*qwaves*25
 ev = df.ws[off:off+nl*4096*4]

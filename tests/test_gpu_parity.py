@@ -236,8 +236,9 @@ def test_kitti_geometries_sampled(torch_, oracle, synth, geom):
 
 
 def test_knn_mfma_path_equals_exact_kernel(torch_, synth, monkeypatch):
-    """The MFMA-screened search and the brute-force VALU kernel (DFLOW_KNN=exact) give identical outputs, also where the
-    screen has to hand work back: negative descriptor values force the exact fix-up pass."""
+    """The MFMA-screened search and the brute-force VALU kernel (DFLOW_KNN=exact) give identical outputs, also for
+    descriptors DAISY never produces (negative values) and where the screen has to hand the whole pass back to the exact
+    fix-up kernel (values outside the f16 range, NaN-free)."""
     H, W, ch, cw = 96, 128, 12, 16
     img1, img2, _ = synth.make_pair(H, W, seed=5, amp_x=8, amp_y=6)
     df = make(H, W, ch, cw)
@@ -256,8 +257,12 @@ def test_knn_mfma_path_equals_exact_kernel(torch_, synth, monkeypatch):
     a, b = run(None, d1, d2), run("exact", d1, d2)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
-    # negative values (never produced by DAISY): outside the premises of the f16 error bound -> whole pass via fix-up
     d1n = d1 - 0.01
+    a, b = run(None, d1n, d2), run("exact", d1n, d2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # one value far outside the f16 range of the scaled, centred rows -> flag -> whole pass via the fix-up kernel
+    d1n = d1.clone(); d1n[H // 2, W // 2, 7] = 2000.0
     a, b = run(None, d1n, d2), run("exact", d1n, d2)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
