@@ -452,9 +452,15 @@ __global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve
         for (int e = 8; e < n; e++) expand(ev[e * 64]);
         lane_ovf |= nev > KM_EVLIST;
         nev = min(nev, KM_EVLIST);
+        // The two half-lanes of a query (lane, lane ^ 32) hold the same descriptor and screened different tile rows: their
+        // lists are pooled (this half's entries first for half 0, the partner's first for half 1 -- any split works, the
+        // top-5 are merged below) and dealt out alternately, so both lanes evaluate half of the query's events.
+        const int nmine = nev, nother = __shfl_xor(nev, 32);
+        const int n0 = half == 0 ? nmine : nother, ntot = nmine + nother;      // n0 = entries of the half-0 lane
+        const int l0 = lane & 31;
         // ---- canonical distance (sequential fmaf chain) and L1 cost (numpy pairwise order) of every listed candidate
-        for (int r = 0; r < nev; r++) {
-            const int idx = evl[r][lane];
+        for (int e = half; e < ntot; e += 2) {
+            const int idx = e < n0 ? evl[e][l0] : evl[e - n0][l0 + 32];
             const float4 *c4 = reinterpret_cast<const float4 *>(p.d2 + ((size_t)(cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * DFLOW_DESC);
             // The partial sums of the chain never decrease, so it stops once it exceeds the lane's current 5th best:
             // such a candidate cannot enter the top 5 (it is then not inserted).  All 17 float4 of the row are fetched at once:
