@@ -268,6 +268,46 @@ def test_knn_mfma_path_equals_exact_kernel(torch_, synth, monkeypatch):
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("case", ("quantised", "tiny", "offset", "constant", "mixed_scale", "sparse"))
+def test_knn_mfma_screen_is_exact_on_hard_descriptors(torch_, synth, monkeypatch, case):
+    """The f16 screen must never lose an exact neighbour: descriptor sets that stress its error bound (exact ties, f16
+    subnormals, a large common offset, identical rows, 1000:1 scale differences between dimensions, mostly-zero rows)
+    against the brute-force kernel, bit for bit."""
+    torch = torch_
+    H, W, ch, cw = 72, 96, 12, 16
+    img1, img2, _ = synth.make_pair(H, W, seed=17, amp_x=6, amp_y=5)
+    df = make(H, W, ch, cw)
+    df.load_pair(img1, img2)
+    d1, d2 = df.descrs1.clone(), df.descrs2.clone()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    if case == "quantised":              # values on a coarse grid: many exactly equal distances -> index tie-breaks
+        d1, d2 = torch.round(d1 * 64) / 64, torch.round(d2 * 64) / 64
+    elif case == "tiny":                 # 64 x lands in the f16 subnormal range
+        d1, d2 = d1 * 1e-5, d2 * 1e-5
+    elif case == "offset":               # large common component, small differences
+        d1, d2 = d1 + 3.0, d2 + 3.0
+    elif case == "constant":             # all candidates identical: every distance ties
+        d2 = d2[:1, :1].expand_as(d2).contiguous()
+    elif case == "mixed_scale":
+        sc = torch.logspace(-2, 1, 68).to(d1.device)
+        d1, d2 = d1 * sc, d2 * sc
+    elif case == "sparse":
+        m = (torch.rand(d2.shape, generator=g) < 0.1).to(d1.device)
+        d1, d2 = d1 * m, d2 * m
+
+    def run(mode):
+        if mode:
+            monkeypatch.setenv("DFLOW_KNN", mode)
+        else:
+            monkeypatch.delenv("DFLOW_KNN", raising=False)
+        df.set_descriptors(d1, d2)
+        df.generisi()
+        return df.host_state()
+    a, b = run(None), run("exact")
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (case, k)
+
+
 def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
     """The two drop-in CLIs on a synthetic pair: file names, dtypes and contents as the reference writes them."""
     import runpy, sys, os
