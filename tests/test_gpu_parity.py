@@ -308,6 +308,48 @@ def test_knn_mfma_screen_is_exact_on_hard_descriptors(torch_, synth, monkeypatch
         assert np.array_equal(a[k], b[k]), (case, k)
 
 
+def test_large_frame_invariants(torch_, oracle, synth):
+    """1920x1080 (2.07 Mpx, 36 GB workspace): 64-bit offsets everywhere, structural invariants and sampled parity with the
+    oracle's exact search; guards against 32-bit index arithmetic that the benchmark sizes cannot reach."""
+    torch = torch_
+    H, W = 1080, 1920
+    img1, img2, _ = synth.make_pair(H, W, seed=31, amp_x=30.0, amp_y=20.0)
+    df = make(H, W)
+    p = oracle_params(oracle, df)
+    df.load_pair(img1, img2)
+    df.generisi()
+    g = dict(ch=df.p.cellh, cw=df.p.cellw, ncx=W // df.p.cellw, ncy=H // df.p.cellh)
+
+    def labels_of(y, x):         # (150,2) int [dy,dx] of one pixel, without converting the whole 5 GB state
+        packed = df.proposals[y, x, :150].cpu().numpy().view(np.uint32)
+        return np.stack([(packed & 0xFFFF).astype(np.uint16).view(np.int16), (packed >> 16).astype(np.uint16).view(np.int16)], -1).astype(np.int64)
+    cy = np.minimum(np.arange(H) // g["ch"], g["ncy"] - 1); cx = np.minimum(np.arange(W) // g["cw"], g["ncx"] - 1)
+    wy = np.minimum(g["ncy"] - 1, cy + 2) - np.maximum(0, cy - 2) + 1
+    wx = np.minimum(g["ncx"] - 1, cx + 2) - np.maximum(0, cx - 2) + 1
+    assert np.array_equal(df.nprop.cpu().numpy(), 5 * wy[:, None] * wx[None, :])
+    # sampled exact searches (bottom-right corner cell included: the largest offsets)
+    d1 = df.descrs1.cpu().numpy(); d2 = df.descrs2.cpu().numpy()
+    rng = np.random.default_rng(1)
+    for (y, x) in [(H - 1, W - 1), (0, 0), (H // 2, W // 2)] + [(int(rng.integers(H)), int(rng.integers(W))) for _ in range(5)]:
+        qcj, qci = int(cy[y]), int(cx[x])
+        mine = labels_of(y, x)
+        slot = 0
+        for ci in range(max(0, qci - 2), min(g["ncx"] - 1, qci + 2) + 1):
+            for cj in range(max(0, qcj - 2), min(g["ncy"] - 1, qcj + 2) + 1):
+                idx, _ = oracle.knn_cell(p, d1[y, x], d2, ci, cj)
+                x0, y0 = ci * g["cw"], cj * g["ch"]
+                cwid = (W if ci == g["ncx"] - 1 else x0 + g["cw"]) - x0
+                exp = np.stack([y0 + idx // cwid - y, x0 + idx % cwid - x], -1)
+                assert np.array_equal(mine[slot:slot + 5], exp), (y, x, ci, cj)
+                slot += 5
+    df.nasumicni()
+    df.ceoBCD(1)
+    bl = df.bestlabels.cpu().numpy(); npr = df.nprop.cpu().numpy()
+    assert (bl >= 0).all() and (bl < npr).all() and npr.max() <= 150
+    flow = df.vratiKonacniFlow().cpu().numpy()
+    assert np.isfinite(flow).all() and np.abs(flow[..., 0]).max() <= 3 * g["ch"] + 25 and np.abs(flow[..., 1]).max() <= 3 * g["cw"] + 25
+
+
 def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
     """The two drop-in CLIs on a synthetic pair: file names, dtypes and contents as the reference writes them."""
     import runpy, sys, os
