@@ -197,41 +197,8 @@ __device__ static inline void wave_min_lane0(Cand &pm)
 }
 
 
-// Minimum of a 64-bit key over the wave (keys = bit patterns of positive doubles, which order like the doubles) and
-// the first lane that attains it: 4 DPP steps inside the rows of 16 lanes, the row leaders through v_readlane, then
-// one ballot.  Returns the minimum in every lane, *first_lane likewise.
-template <int CTRL> __device__ static inline uint32_t u32_dpp_min(uint32_t x)
-{
-    // lanes without a source keep their own value (bound_ctrl = false, old = self); fuses into v_min_u32_dpp
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
-    return o < x ? o : x;
-}
-// minimum of a 32-bit value over the wave, wave-uniform result: 4 DPP steps inside the rows of 16 lanes, then the row
-// leaders through v_readlane and scalar minima
-__device__ static inline uint32_t wave_u32_min(uint32_t x)
-{
-    x = u32_dpp_min<DPP_ROW_SHL1>(x);
-    x = u32_dpp_min<DPP_ROW_SHL2>(x);
-    x = u32_dpp_min<DPP_ROW_SHL4>(x);
-    x = u32_dpp_min<DPP_ROW_SHL8>(x);
-    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
-    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
-    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
-    return ab < cd ? ab : cd;
-}
 // Minimum of a 64-bit key over the wave (keys = bit patterns of positive doubles, which order like the doubles) and the
 // first lane that attains it: high words first, then the low words of the lanes that tie on the high word.
-__device__ static inline unsigned long long wave_key_min(unsigned long long key, int *first_lane)
-{
-    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-    const uint32_t mh = wave_u32_min(hi);
-    const uint32_t ml = wave_u32_min(hi == mh ? lo : 0xFFFFFFFFu);
-    const unsigned long long hit = __ballot(hi == mh && lo == ml);
-    *first_lane = __ffsll((long long)hit) - 1;
-    return ((unsigned long long)mh << 32) | ml;
-}
-
-
 // minimum of a 32-bit value over the wave, wave-uniform result: 4 fused DPP minima inside the rows of 16 lanes (lanes
 // without a source keep their own value; s_nop 1 = the two wait states a DPP read of a fresh VALU result needs), then
 // the row leaders through v_readlane and scalar minima

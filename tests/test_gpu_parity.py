@@ -394,3 +394,28 @@ def test_batch_driver_config3(torch_, oracle, synth, tmp_path):
     assert np.array_equal(got, O.fb_consistency(fwd, bwd, 3))
     assert np.array_equal(np.load(os.path.join(tmp_path, "Gotova flow slika 100 backward=1 posle 02 BCD.npy")), bwd)
     assert os.path.getsize(os.path.join(tmp_path, "parovi_00.txt")) > 0
+
+
+def test_bench_contract(torch_, tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object (dominant kernel + per-stage fractions) and
+    the CPU baseline; run as a child process, as the driver does."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("Mpix/s") and d["unit"] == "Mpix/s" and d["n_gpus"] == 1 and d["steps"] == 3
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 436 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] == "bcd_chain_kernel" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1 and r["traffic"] > 0
+    assert set(("daisy", "knn", "bcd", "end_to_end")) <= set(r["stages"])
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mpix/s" and 0 < c["value"] < d["value"]
