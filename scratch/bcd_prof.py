@@ -10,7 +10,7 @@ img1, img2, gt = synth.make_pair(H, W, seed=2022)
 df = pl.DiscreteFlow(H, W, seed=99)
 df.load_pair(torch.from_numpy(img1).cuda(), torch.from_numpy(img2).cuda()); df.generisi(); df.nasumicni(); df.pakovanje()
 L = _lib.lib()
-names = ["fetch", "perm/small", "list8 #1", "list8 #2", "residual", "dp write", "wave min", "barrier"]
+names = ["issue reads", "precompute+fetch", "first 8", "next 4+4", "residual", "dp write", "wave min", "barrier"]
 for ph in (1, 0):
     torch.cuda.synchronize(); L.dflow_debug_bcd_prof_reset()
     df.bcd_phase(ph); torch.cuda.synchronize()
