@@ -149,7 +149,7 @@ struct BcdArgs {
     const int32_t *nprop;
     int32_t *bestlabels;
     const uint32_t *masks, *recs;
-    uint8_t *back;
+    uint8_t *back, *back_trash;
 };
 
 struct Cand {
@@ -225,11 +225,10 @@ __device__ static inline unsigned long long wave_key_min_asm(unsigned long long 
     const uint32_t mh = wave_u32_min_asm(hi);
     const unsigned long long tie = __ballot(hi == mh);
     uint32_t ml; int fl;
-    if (__popcll(tie) == 1) {
-        // one lane alone has the smallest high word (the usual case): it is the minimum
-        fl = __ffsll((long long)tie) - 1;
-        ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, fl);
-    } else {
+    // one lane alone has the smallest high word (the usual case): it is the minimum
+    fl = __ffsll((long long)tie) - 1;
+    ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, fl);
+    if (__builtin_expect(__popcll(tie) != 1, 0)) {
         ml = wave_u32_min_asm(hi == mh ? lo : 0xFFFFFFFFu);
         fl = __ffsll((long long)__ballot(hi == mh && lo == ml)) - 1;
     }
@@ -333,7 +332,8 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
 
     PROF_DECL
     int pn = tnl[0];
-    uint8_t *backp = a.back + (size_t)chain * len * LP + tl;          // + i*LP per step
+    uint8_t *backp = owner ? a.back + (size_t)chain * len * LP + tl : a.back_trash + (tid - DFLOW_MAX_LABELS);   // + i*LP per step
+    const uint32_t bstride = owner ? (uint32_t)LP : 0u;
     // What a step needs besides the previous pixel's dp does not depend on the recursion: it is computed one step ahead,
     // in the shadow of the LDS reads of the running step (the wave is alone on its SIMD: nothing else hides that latency).
     struct Pre {
@@ -343,7 +343,9 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         uint32_t rlw, Fc;       // list word of entries 12..15; the label's biased flow
         uint32_t pw1;           // cost nibbles 8..15 | more-than-16 flag
         int tn;
-        bool act, more8, more12, more16;
+        bool act, more16;
+        bool any12;             // wave-uniform: some row of this wave has more than 12 members (known a step ahead: the branch on it
+                                // does not wait for the vector unit)
     };
     auto precompute = [&](const int i, const StepIn &in) __attribute__((always_inline)) {
         Pre p;
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         const uint32_t s2 = min(lim2, flow_l1_biased(p.Fc, bestf[im]));
         p.small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
         p.act = owner && tl < p.tn;
-        p.more8 = p.act && (rl.z & 0xFFu) != 0xFFu; p.more12 = p.act && (rl.w & 0xFFu) != 0xFFu; p.more16 = p.act && (int)p.pw1 < 0;
+        p.any12 = __ballot(p.act && (rl.w & 0xFFu) != 0xFFu) != 0ull; p.more16 = p.act && (int)p.pw1 < 0;
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const uint32_t w = j < 4 ? rl.x : (j < 8 ? rl.y : rl.z);
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
             }
             PROF(2)
             // few rows have more than 12 members (wave-uniform branch on the longest row of the wave), fewer still more than 16
-            if (__ballot(me.more12)) {
+            if (__builtin_expect(me.any12, 0)) {
                 {
                     uint32_t ad[4]; double d4[4];
 #pragma unroll
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
                     }
                 }
                 PROF(3)
-                if (__ballot(me.more16)) {
+                if (__builtin_expect(__ballot(me.more16) != 0ull, 0)) {
                 // some rows are denser still: those lanes fetch their 160-bit row and walk what is left behind the 16th
                 // list entry, four set bits per round; still increasing k, so strict '<' stands
                 const uint32_t Fc = me.Fc;
@@ -470,16 +472,19 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
             }
         }
         PROF(4)
-        unsigned long long key = ~0ull;
-        if (me.act) {
+        // No branch on `act`: the slots of labels beyond this pixel's count (dp, flow, back-pointer) may hold anything, no
+        // list and no traceback refers to them; the shadow lanes (tid >= 160) write to LDS slots 160..191 (equally
+        // unreferenced) and to a trash line behind the back-pointer array.
+        unsigned long long key;
+        {
             const bool found = besta != 0x7fffffffu;
             const double mincost = found ? bestv : perm.v;
             const int pl = found ? (int)(besta >> 3) : perm.k;
             const double dpc = __dadd_rn(mincost, me.small);
-            s_dp[CUR * BCD_LDS_LABELS + tl] = dpc;
-            s_fp[CUR * BCD_LDS_LABELS + tl] = me.Fc;
-            backp[(size_t)i * LP] = (uint8_t)pl;
-            key = (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, dpc));
+            s_dp[CUR * BCD_LDS_LABELS + tid] = dpc;
+            s_fp[CUR * BCD_LDS_LABELS + tid] = me.Fc;
+            backp[(size_t)i * bstride] = (uint8_t)pl;
+            key = me.act ? (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, dpc)) : ~0ull;
         }
         PROF(5)
         {
@@ -564,7 +569,7 @@ static size_t back_bytes(const dflow_params *p)
         size_t b = (size_t)n * len * p->label_pitch;
         if (b > m) m = b;
     }
-    return (m + 255) & ~(size_t)255;
+    return ((m + 255) & ~(size_t)255) + 256;      // + a trash line for the shadow lanes of the chain kernel
 }
 
 static size_t mask_bytes(const dflow_params *p)
@@ -599,7 +604,7 @@ int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const int
     BcdArgs a;
     a.H = p->pich; a.W = p->picw; a.LP = p->label_pitch; a.tpsi = p->tpsi; a.phase = phase; a.lamda = p->lamda;
     a.proposals = proposals; a.nprop = nprop; a.bestlabels = bestlabels;
-    a.back = (uint8_t *)ws; a.masks = (const uint32_t *)((char *)ws + back_bytes(p));
+    a.back = (uint8_t *)ws; a.back_trash = (uint8_t *)ws + back_bytes(p) - 256; a.masks = (const uint32_t *)((char *)ws + back_bytes(p));
     a.recs = (const uint32_t *)((char *)ws + back_bytes(p) + mask_bytes(p));
     size_t shmem = (size_t)(len + 2) * sizeof(uint32_t) + (size_t)len * sizeof(int);
     hipLaunchKernelGGL(bcd_chain_kernel, dim3(nchains), dim3(BCD_THREADS), shmem, s, a);

@@ -12,7 +12,7 @@ def back_bytes():
     m = 0
     for n, ln in (((W + 1) // 2, H), ((H + 1) // 2, W), (W // 2, H), (H // 2, W)):
         m = max(m, n * ln * LP)
-    return (m + 255) & ~255
+    return ((m + 255) & ~255) + 256
 off = back_bytes() + H * W * 2 * LP * 5 * 4
 rows = slice(100, 140)                       # a band of image rows
 nprop = df.nprop.cpu().numpy()
