@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         return r;
     };
     const StepIn S0 = fetch(0);
-    StepIn A = fetch(1), B = fetch(2), C = fetch(3), D = fetch(4);
+    StepIn A = fetch(1), B = fetch(2), C = fetch(3);
 
     // ---- chain start: dp[0,tl] = (s1 + s2) + lamda*lcost   (python bcd.py:118-120)
     {
@@ -334,141 +334,115 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     int pn = tnl[0];
     uint8_t *backp = owner ? a.back + (size_t)chain * len * LP + tl : a.back_trash + (tid - DFLOW_MAX_LABELS);   // + i*LP per step
     const uint32_t bstride = owner ? (uint32_t)LP : 0u;
-    // What a step needs besides the previous pixel's dp does not depend on the recursion: it is computed one step ahead,
-    // in the shadow of the LDS reads of the running step (the wave is alone on its SIMD: nothing else hides that latency).
-    struct Pre {
-        uint32_t ad[12];        // dp offsets 8 k of the first 12 compatible predecessors (0xFF -> the +inf tail)
-        double pd[12];          // their pair costs
-        double small;           // (lamda*lcost + s1) + s2, python bcd.py:161-162 (a side neighbour outside the chain: 0)
-        uint32_t rlw, Fc;       // list word of entries 12..15; the label's biased flow
-        uint32_t pw1;           // cost nibbles 8..15 | more-than-16 flag
-        int tn;
-        bool act, more16;
-        bool any12;             // wave-uniform: some row of this wave has more than 12 members (known a step ahead: the branch on it
-                                // does not wait for the vector unit)
-    };
-    auto precompute = [&](const int i, const StepIn &in) __attribute__((always_inline)) {
-        Pre p;
-        const int ic = min(i, len - 1);                          // past the end: harmless values, never used
-        p.tn = tnl[ic];
-        const uint4 rl = in.rl;
-        const uint32_t pw0 = in.px.x;
-        p.pw1 = in.px.y; p.Fc = in.px.z; p.rlw = rl.w;
-        const float lc = __uint_as_float(in.px.w);
-        const int ip = ic + dirp, im = ic - dirp;
-        const uint32_t lim1 = (ip >= 0 && ip < len) ? tpsi : 0u, lim2 = (im >= 0 && im < len) ? tpsi : 0u;
-        const uint32_t s1 = min(lim1, flow_l1_biased(p.Fc, bestf[ip]));
-        const uint32_t s2 = min(lim2, flow_l1_biased(p.Fc, bestf[im]));
-        p.small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
-        p.act = owner && tl < p.tn;
-        p.any12 = __ballot(p.act && (rl.w & 0xFFu) != 0xFFu) != 0ull; p.more16 = p.act && (int)p.pw1 < 0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const uint32_t w = j < 4 ? rl.x : (j < 8 ? rl.y : rl.z);
-            p.ad[j] = ((w >> (8 * (j & 3))) & 0xFFu) << 3;
-            p.pd[j] = (double)(((j < 8 ? pw0 : p.pw1) >> (4 * (j & 7))) & 7u);
-        }
-        return p;
-    };
-    // One step of the chain; CUR (compile-time) is the LDS buffer this step writes, CUR^1 holds the previous pixel.  The
-    // record slots A..D are used round-robin by the 4x unrolled loop below (refilled with the record of step i+4 right
-    // after the precompute of step i+1 has consumed its slot), so prefetched registers are never copied while their loads
-    // are still in flight; the precomputed state alternates between two register sets.
-    auto step = [&](auto curc, const int i, const Pre &me, Pre &next, StepIn &nextin, StepIn &refill) __attribute__((always_inline)) {
+    // One step of the chain; CUR (compile-time) is the LDS buffer this step writes, CUR^1 holds the previous pixel.  `in`
+    // is consumed first and then refilled with the record of step i+3: the three slots are used round-robin by the 6x
+    // unrolled loop below, so prefetched registers are never copied while their loads are still in flight (a register
+    // rotation A=B, B=C would make every step wait for the loads it has just issued).  The common path of a step is one
+    // basic block (the wave is alone on its SIMD: every wave-uniform branch costs more than a few wasted instructions).
+    auto step = [&](auto curc, const int i, StepIn &in) __attribute__((always_inline)) {
         constexpr int CUR = decltype(curc)::value;
         const char *prev = reinterpret_cast<const char *>(s_dp + (CUR ^ 1) * BCD_LDS_LABELS);
         const uint32_t *fprev = s_fp + (CUR ^ 1) * BCD_LDS_LABELS;
         PROF_START
+        const int tn = tnl[i];
+        const uint4 rl = in.rl;
+        const uint32_t pw0 = in.px.x, pw1 = in.px.y, Fc = in.px.z;
+        const float lc = __uint_as_float(in.px.w);
+        const bool act = owner && tl < tn;
+        in = fetch(i + 3);
+        PROF(0)
         // min over compatible previous labels (python bcd.py:163-176 / :198-219) in increasing k (strict '<' keeps the
         // first minimum).  The first 16 compatible predecessors of every row come as a byte list in increasing k (0xFF =
         // none, which reads the +inf tail of dp) together with their pair costs; the LDS reads of the first 12 are issued
-        // at once (most waves need 9 to 12), then the partials of permmincost / permminlabel (python bcd.py:152-157)
-        // of the previous step (waves are in label order, every partial index is the first one inside its wave).
-        double dd[12];
+        // at once (most waves need 9 to 12; a wave-uniform exit after 8 costs as much as it saves).  Candidates are
+        // tracked by their dp offset 8 k.
+        uint32_t ad[12]; double dd[12];
 #pragma unroll
-        for (int j = 0; j < 12; j++) dd[j] = *reinterpret_cast<const double *>(prev + me.ad[j]);
-        const unsigned long long p0 = permv[(CUR ^ 1) * 4], p1 = permv[(CUR ^ 1) * 4 + 1], p2 = permv[(CUR ^ 1) * 4 + 2];
-        const int i0 = permi[(CUR ^ 1) * 4], i1 = permi[(CUR ^ 1) * 4 + 1], i2 = permi[(CUR ^ 1) * 4 + 2];
-        PROF(0)
-        // in the shadow of those reads: everything step i+1 needs that does not depend on dp, and the prefetch of step i+4
-        __builtin_amdgcn_sched_barrier(0);               // keep the reads above in front
-        next = precompute(i + 1, nextin);
-        refill = fetch(i + 4);
-        // pin the precomputed values here: the compiler would otherwise sink them to their first use, behind the barrier
-        // and in front of the next step's reads
-#pragma unroll
-        for (int j = 0; j < 12; j++) { asm volatile("" : "+v"(next.ad[j])); asm volatile("" : "+v"(next.pd[j])); }
-        asm volatile("" : "+v"(next.small));
-        __builtin_amdgcn_sched_barrier(0);
-        PROF(1)
+        for (int j = 0; j < 12; j++) {
+            const uint32_t w = j < 4 ? rl.x : (j < 8 ? rl.y : rl.z);
+            ad[j] = ((w >> (8 * (j & 3))) & 0xFFu) << 3;
+            dd[j] = *reinterpret_cast<const double *>(prev + ad[j]);
+        }
+        // permmincost / permminlabel (python bcd.py:152-157) merged from the per-wave partials of the previous step (waves
+        // are in label order and every partial index is the first one inside its wave), and the unary term
+        // small = (lamda*lcost + s1) + s2 (python bcd.py:161-162; a side neighbour outside the chain contributes 0)
         Cand perm;
+        double small;
         {
+            const unsigned long long p0 = permv[(CUR ^ 1) * 4], p1 = permv[(CUR ^ 1) * 4 + 1], p2 = permv[(CUR ^ 1) * 4 + 2];
+            const int i0 = permi[(CUR ^ 1) * 4], i1 = permi[(CUR ^ 1) * 4 + 1], i2 = permi[(CUR ^ 1) * 4 + 2];
+            const int ip = i + dirp, im = i - dirp;
+            const uint32_t lim1 = (ip >= 0 && ip < len) ? tpsi : 0u, lim2 = (im >= 0 && im < len) ? tpsi : 0u;
+            const uint32_t s1 = min(lim1, flow_l1_biased(Fc, bestf[ip]));
+            const uint32_t s2 = min(lim2, flow_l1_biased(Fc, bestf[im]));
             unsigned long long pmn = p0; int pix_ = i0;
             if (p1 < pmn) { pmn = p1; pix_ = i1; }
             if (p2 < pmn) { pmn = p2; pix_ = i2; }
             perm.v = __longlong_as_double((long long)pmn); perm.k = pix_;
+            small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
         }
+        PROF(1)
         double bestv = 1e300; uint32_t besta = 0x7fffffffu;
         {
 #pragma unroll
-            for (int j = 0; j < 12; j++) {             // 12 unconditionally: a wave-uniform exit after 8 costs as much as it saves
-                const double c = __dadd_rn(dd[j], me.pd[j]);
+            for (int j = 0; j < 12; j++) {
+                const double c = __dadd_rn(dd[j], (double)(((j < 8 ? pw0 : pw1) >> (4 * (j & 7))) & 7u));
                 const bool t = c < bestv;               // +inf + psi = +inf never wins
-                bestv = __builtin_fmin(bestv, c); besta = t ? me.ad[j] : besta;
+                bestv = __builtin_fmin(bestv, c); besta = t ? ad[j] : besta;
             }
             PROF(2)
             // few rows have more than 12 members (wave-uniform branch on the longest row of the wave), fewer still more than 16
-            if (__builtin_expect(me.any12, 0)) {
+            if (__builtin_expect(__ballot(act && (rl.w & 0xFFu) != 0xFFu) != 0ull, 0)) {
                 {
-                    uint32_t ad[4]; double d4[4];
+                    uint32_t a4[4]; double d4[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { ad[j] = ((me.rlw >> (8 * j)) & 0xFFu) << 3; d4[j] = *reinterpret_cast<const double *>(prev + ad[j]); }
+                    for (int j = 0; j < 4; j++) { a4[j] = ((rl.w >> (8 * j)) & 0xFFu) << 3; d4[j] = *reinterpret_cast<const double *>(prev + a4[j]); }
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const double c = __dadd_rn(d4[j], (double)((me.pw1 >> (4 * (4 + j))) & 7u));
+                        const double c = __dadd_rn(d4[j], (double)((pw1 >> (4 * (4 + j))) & 7u));
                         const bool t = c < bestv;
-                        bestv = __builtin_fmin(bestv, c); besta = t ? ad[j] : besta;
+                        bestv = __builtin_fmin(bestv, c); besta = t ? a4[j] : besta;
                     }
                 }
                 PROF(3)
-                if (__builtin_expect(__ballot(me.more16) != 0ull, 0)) {
-                // some rows are denser still: those lanes fetch their 160-bit row and walk what is left behind the 16th
-                // list entry, four set bits per round; still increasing k, so strict '<' stands
-                const uint32_t Fc = me.Fc;
-                const int k15 = (int)(me.rlw >> 24);
-                const size_t rowidx = ((size_t)(pix0 + i * pstep) * 2 + dir) * LP + tl;
-                const uint32_t *mrow = a.masks + rowidx * BCD_MASK_WORDS;
-                unsigned long long w0 = 0, w1 = 0, w2 = 0;
-                if (me.more16) {
-                    w0 = (unsigned long long)mrow[0] | ((unsigned long long)mrow[1] << 32);
-                    w1 = (unsigned long long)mrow[2] | ((unsigned long long)mrow[3] << 32);
-                    w2 = (unsigned long long)mrow[4];
-                    const int b = k15 & 63;
-                    const unsigned long long keep = b == 63 ? 0ull : (~0ull << (b + 1));
-                    if (k15 < 64) w0 &= keep; else if (k15 < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
-                }
-                int base = 0;
-                auto next_bit = [&](bool &valid) {
-                    if (w0 == 0) { w0 = w1; w1 = w2; w2 = 0; base += 64; if (w0 == 0) { w0 = w1; w1 = 0; base += 64; } }
-                    valid = w0 != 0;
-                    int k = 0;
-                    if (valid) { k = base + __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
-                    return k;
-                };
-                while (w0 | w1 | w2) {
-                    bool v[4]; int kk[4]; double d4[4]; uint32_t ff[4];
+                const bool more16 = act && (int)pw1 < 0;
+                if (__builtin_expect(__ballot(more16) != 0ull, 0)) {
+                    // some rows are denser still: those lanes fetch their 160-bit row and walk what is left behind the 16th
+                    // list entry, four set bits per round; still increasing k, so strict '<' stands
+                    const int k15 = (int)(rl.w >> 24);
+                    const size_t rowidx = ((size_t)(pix0 + i * pstep) * 2 + dir) * LP + tl;
+                    const uint32_t *mrow = a.masks + rowidx * BCD_MASK_WORDS;
+                    unsigned long long w0 = 0, w1 = 0, w2 = 0;
+                    if (more16) {
+                        w0 = (unsigned long long)mrow[0] | ((unsigned long long)mrow[1] << 32);
+                        w1 = (unsigned long long)mrow[2] | ((unsigned long long)mrow[3] << 32);
+                        w2 = (unsigned long long)mrow[4];
+                        const int b = k15 & 63;
+                        const unsigned long long keep = b == 63 ? 0ull : (~0ull << (b + 1));
+                        if (k15 < 64) w0 &= keep; else if (k15 < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
+                    }
+                    int base = 0;
+                    auto next_bit = [&](bool &valid) {
+                        if (w0 == 0) { w0 = w1; w1 = w2; w2 = 0; base += 64; if (w0 == 0) { w0 = w1; w1 = 0; base += 64; } }
+                        valid = w0 != 0;
+                        int k = 0;
+                        if (valid) { k = base + __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
+                        return k;
+                    };
+                    while (w0 | w1 | w2) {
+                        bool v[4]; int kk[4]; double d4[4]; uint32_t ff[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) kk[j] = next_bit(v[j]);
+                        for (int j = 0; j < 4; j++) kk[j] = next_bit(v[j]);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { d4[j] = *reinterpret_cast<const double *>(prev + 8 * kk[j]); ff[j] = fprev[kk[j]]; }   // invalid slots read label 0: harmless
+                        for (int j = 0; j < 4; j++) { d4[j] = *reinterpret_cast<const double *>(prev + 8 * kk[j]); ff[j] = fprev[kk[j]]; }   // invalid slots read label 0: harmless
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const double c = __dadd_rn(d4[j], (double)flow_l1_biased(Fc, ff[j]));
-                        const bool t = v[j] && c < bestv;
-                        bestv = t ? c : bestv; besta = t ? (uint32_t)kk[j] << 3 : besta;
+                        for (int j = 0; j < 4; j++) {
+                            const double c = __dadd_rn(d4[j], (double)flow_l1_biased(Fc, ff[j]));
+                            const bool t = v[j] && c < bestv;
+                            bestv = t ? c : bestv; besta = t ? (uint32_t)kk[j] << 3 : besta;
+                        }
                     }
                 }
-            }
             }
         }
         PROF(4)
@@ -480,11 +454,11 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
             const bool found = besta != 0x7fffffffu;
             const double mincost = found ? bestv : perm.v;
             const int pl = found ? (int)(besta >> 3) : perm.k;
-            const double dpc = __dadd_rn(mincost, me.small);
+            const double dpc = __dadd_rn(mincost, small);
             s_dp[CUR * BCD_LDS_LABELS + tid] = dpc;
-            s_fp[CUR * BCD_LDS_LABELS + tid] = me.Fc;
+            s_fp[CUR * BCD_LDS_LABELS + tid] = Fc;
             backp[(size_t)i * bstride] = (uint8_t)pl;
-            key = me.act ? (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, dpc)) : ~0ull;
+            key = act ? (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, dpc)) : ~0ull;
         }
         PROF(5)
         {
@@ -499,21 +473,22 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         PROF(7)
-        pn = me.tn;
+        pn = tn;
     };
-    // step i consumes the record slot (i-1)%4 through its precomputed state; during step i the state of step i+1 is
-    // computed from slot i%4 (fetched three steps earlier), and slot (i-1)%4 is refilled with the record of step i+4
-    Pre P0 = precompute(1, A), P1;
     int i = 1;
-    for (; i + 3 < len; i += 4) {                       // whole groups of four without per-step bounds checks
-        step(IntC<1>(), i, P0, P1, B, A);
-        step(IntC<0>(), i + 1, P1, P0, C, B);
-        step(IntC<1>(), i + 2, P0, P1, D, C);
-        step(IntC<0>(), i + 3, P1, P0, A, D);
+    for (; i + 5 < len; i += 6) {                       // whole groups of six without per-step bounds checks
+        step(IntC<1>(), i, A);
+        step(IntC<0>(), i + 1, B);
+        step(IntC<1>(), i + 2, C);
+        step(IntC<0>(), i + 3, A);
+        step(IntC<1>(), i + 4, B);
+        step(IntC<0>(), i + 5, C);
     }
-    if (i < len) step(IntC<1>(), i, P0, P1, B, A);
-    if (i + 1 < len) step(IntC<0>(), i + 1, P1, P0, C, B);
-    if (i + 2 < len) step(IntC<1>(), i + 2, P0, P1, D, C);
+    if (i < len) step(IntC<1>(), i, A);
+    if (i + 1 < len) step(IntC<0>(), i + 1, B);
+    if (i + 2 < len) step(IntC<1>(), i + 2, C);
+    if (i + 3 < len) step(IntC<0>(), i + 3, A);
+    if (i + 4 < len) step(IntC<1>(), i + 4, B);
 #ifdef BCD_PROF
     if (blockIdx.x == 7 && lane == 0) for (int k = 0; k < 8; k++) g_bcd_prof[wave][k] += pacc[k];
 #endif
