@@ -209,10 +209,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # HBM-side bytes per launch from rocprofv3 --pmc (one counter per pass, profiles/r01_pmc_traffic.txt):
-                         # FETCH_SIZE 598080 KB, doubled as MI355X_MICROARCH.md prescribes for gfx950's wide (16 B/lane) reads,
-                         # + WRITE_SIZE 33645 KB.  Expected from the access pattern: 1.14 GB of 32-byte label records (160 rows
+                         # FETCH_SIZE 598299 KB, doubled as MI355X_MICROARCH.md prescribes for gfx950's wide (16 B/lane) reads,
+                         # + WRITE_SIZE 39138 KB.  Expected from the access pattern: 1.14 GB of 32-byte label records (160 rows
                          # per visited pixel: the compat lists the reference keeps in packedksets ride along) + 36 MB back-pointers
-                         "traffic": (2 * 598080 + 33645) * 1024,
+                         "traffic": (2 * 598299 + 39138) * 1024,
                          "launch_ms": bcd_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "serial Viterbi chains (218-512 workgroups x 436-1024 dependent steps): latency-bound, "
                                  "not bandwidth-bound; launch_ms is measured with %d pairs in flight" % P},
