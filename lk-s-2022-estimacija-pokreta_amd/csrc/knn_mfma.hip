@@ -68,6 +68,23 @@ __device__ static inline size_t list_id(const KmGeom &a, int qcell, int qwave, i
 }
 
 // ------------------------------------------------------------------------------------------------ prep
+// Candidate (image 2) rows are stored cell by cell in TILE POSITION order, every cell padded to whole chunks: position
+// (tile, row) of cell c holds candidate row * ntiles + tile of that cell (see the screen kernel), positions without a
+// candidate hold the sentinel row.  The screen then stages a chunk as one contiguous 15 KB read.
+__host__ __device__ static inline int km_pad(int npts) { return (npts + KM_CHUNK - 1) / KM_CHUNK * KM_CHUNK; }
+__host__ __device__ static inline size_t km_cell_base(const Geom &g, int ci, int cj)
+{
+    const int wl = g.x1(g.ncx - 1) - g.x0(g.ncx - 1), hl = g.y1(g.ncy - 1) - g.y0(g.ncy - 1);
+    const size_t rowsum = (size_t)(g.ncx - 1) * km_pad(g.cw * g.ch) + km_pad(wl * g.ch);      // a regular row of cells
+    const int hj = cj == g.ncy - 1 ? hl : g.ch;
+    return (size_t)cj * rowsum + (size_t)ci * km_pad(g.cw * hj);
+}
+__host__ __device__ static inline size_t km_total_rows(const Geom &g)
+{
+    const int wl = g.x1(g.ncx - 1) - g.x0(g.ncx - 1), hl = g.y1(g.ncy - 1) - g.y0(g.ncy - 1);
+    return km_cell_base(g, 0, g.ncy - 1) + (size_t)(g.ncx - 1) * km_pad(g.cw * hl) + km_pad(wl * hl);
+}
+
 // mu = mean descriptor over KM_MEAN_SAMPLES evenly spaced pixels of image 2: one block, thread = (dimension, sample group),
 // partial sums combined in a fixed order.  Any mu gives exact results; a good one makes the screen tight.
 __global__ void __launch_bounds__(1024) knn_mean_kernel(const float *__restrict__ d, float *__restrict__ mu, int npix)
@@ -89,12 +106,36 @@ __global__ void __launch_bounds__(1024) knn_mean_kernel(const float *__restrict_
     }
 }
 
-// one thread per pixel of one image; which = 0: image 1 (queries), 1: image 2 (candidates)
+// which = 0: image 1 (queries), one thread per pixel, rows in pixel order.  which = 1: image 2 (candidates), one thread
+// per (cell = blockIdx.y, tile position), rows in position order (above).
 __global__ void knn_prep_kernel(const float *__restrict__ d, const float *__restrict__ mu, _Float16 *__restrict__ h,
                                 float2 *__restrict__ qs, int *__restrict__ flags, Geom g, int which)
 {
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= g.H * g.W) return;
+    int pix;
+    size_t orow;
+    if (which == 0) {
+        pix = blockIdx.x * blockDim.x + threadIdx.x;
+        if (pix >= g.H * g.W) return;
+        orow = (size_t)pix;
+    } else {
+        const int ci = blockIdx.y % g.ncx, cj = blockIdx.y / g.ncx;
+        const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0, cnpts = ccw * (g.y1(cj) - cy0);
+        const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+        if (pos >= km_pad(cnpts)) return;
+        orow = km_cell_base(g, ci, cj) + pos;
+        const int ntiles = km_pad(cnpts) / 32;
+        const int idx = (pos & 31) * ntiles + (pos >> 5);
+        if (idx >= cnpts) {
+            // no candidate here: h- = h+ = 60000, everything else 0 -> MFMA value -60000, below every real one (real
+            // h +- S_c lie inside +-50000)
+            float4 *o = reinterpret_cast<float4 *>(h + orow * KM_K);
+            _Float16 z[8] = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+            _Float16 t8[8] = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)60000.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)60000.0f};
+            for (int k = 0; k < KM_K * 2 / 16; k++) o[k] = *reinterpret_cast<const float4 *>(k == 8 ? t8 : z);   // k = 68 and 71
+            return;
+        }
+        pix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
+    }
     const float4 *s = reinterpret_cast<const float4 *>(d + (size_t)pix * DFLOW_DESC);
     _Float16 row[KM_K];
     float ss = 0.0f, sx = 0.0f, se = 0.0f;
@@ -142,16 +183,10 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, const float *__rest
 #pragma unroll
         for (int i = 0; i < 3; i++) { _Float16 pc = (_Float16)r; row[71 + i] = pc; r = r - (float)pc; }
     }
-    float4 *o = reinterpret_cast<float4 *>(h + (size_t)pix * KM_K);
+    float4 *o = reinterpret_cast<float4 *>(h + orow * KM_K);
     const float4 *r4 = reinterpret_cast<const float4 *>(row);
 #pragma unroll
     for (int k = 0; k < KM_K * 2 / 16; k++) o[k] = r4[k];
-    if (which == 1 && pix == 0) {
-        // sentinel row behind the image (row index H*W): h- = h+ = 60000, everything else 0.  Tile rows beyond the end
-        // of a cell are staged from it: their MFMA value is -60000, below every real one (real h +- S_c lie inside +-50000).
-        _Float16 *sr = h + (size_t)g.H * g.W * KM_K;
-        for (int k = 0; k < KM_K; k++) sr[k] = (_Float16)((k == 68 || k == 71) ? 60000.0f : 0.0f);
-    }
     if (bad) atomicOr(flags, 1);
 }
 
@@ -225,24 +260,22 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     }
 
     const int nchunks = (cnpts + KM_CHUNK - 1) / KM_CHUNK;
-    const int ntiles = nchunks * (KM_CHUNK / 32);
+    const size_t cbase = km_cell_base(g, ci, cj);
     // Asynchronous staging of one chunk straight into LDS (global_load_lds_dwordx4: the LDS address is wave-uniform
     // base + 16*lane, the global address is per lane).  The LDS image is 96 rows of 11 16-byte slots (10 data + 1
     // pad = 176-byte pitch) = 1056 slots = 17 wave-instructions (the last one half used; the buffer is 17 KB).
-    // Pad slots re-read part 0; rows beyond the cell read the sentinel row (MFMA value -60000 < every real one).
+    // Pad slots re-read part 0; positions beyond the cell hold sentinel rows (MFMA value -60000 < every real one).
     auto stage = [&](int chunk, int buf) {
         char *base = abuf + (size_t)buf * KM_ABUF;
         for (int ins = wave; ins < 17; ins += KM_WAVES) {
             const int slot = ins * 64 + lane;
             int r = slot / 11, part = slot % 11;
-            // tile position -> candidate: position p = (tile, row) holds candidate row * ntiles + tile, so that the 16 rows
-            // a lane sees of one tile are far apart in the cell.  Neighbouring pixels have similar descriptors: with raster
-            // order several of a query's 5 best would share a lane's tile column, of which only the maximum enters a5.
-            const int pos = chunk * KM_CHUNK + r;
-            const int idx = (pos & 31) * ntiles + (pos >> 5);
+            // the candidate rows are stored in tile position order (knn_prep_kernel): position p = (tile, row) holds
+            // candidate row * ntiles + tile, so that the 16 rows a lane sees of one tile are far apart in the cell.
+            // Neighbouring pixels have similar descriptors: with raster order several of a query's 5 best would share a
+            // lane's tile column, of which only the maximum enters a5.
             if (part > 9) part = 0;
-            const int cpix = idx < cnpts ? (cy0 + idx / ccw) * g.W + cx0 + idx % ccw : g.H * g.W;   // else: sentinel row
-            const char *src = reinterpret_cast<const char *>(p.h2 + (size_t)cpix * KM_K) + part * 16;
+            const char *src = reinterpret_cast<const char *>(p.h2 + (cbase + (size_t)(min(chunk, nchunks - 1) * KM_CHUNK + r)) * KM_K) + part * 16;   // chunks staged past the end (never used) re-read the last one
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(base + ins * 1024), 16, 0, 0);
         }
@@ -576,7 +609,7 @@ size_t knn_mfma_ws_bytes(const dflow_params *p)
 {
     size_t N = (size_t)p->pich * p->picw;
     size_t nl = num_lists(p);
-    return (2 * N + 1) * KM_K * sizeof(_Float16) + N * sizeof(float2) + 1024 +
+    return (N + km_total_rows(make_geom(p))) * KM_K * sizeof(_Float16) + N * sizeof(float2) + 1024 +
            KM_OVF_CAP * sizeof(int4) + nl * (KM_LIST_WORDS * sizeof(uint32_t) + 128) + 1024;
 }
 
@@ -597,7 +630,7 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     auto align256 = [](char *w) { return (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255); };
     char *w = (char *)ws;
     _Float16 *h1 = (_Float16 *)w; w += N * KM_K * sizeof(_Float16);
-    _Float16 *h2 = (_Float16 *)w; w += (N + 1) * KM_K * sizeof(_Float16);   // + sentinel row
+    _Float16 *h2 = (_Float16 *)w; w += km_total_rows(g) * KM_K * sizeof(_Float16);   // position order, padded cells
     float2 *qs = (float2 *)w; w += N * sizeof(float2);
     w = align256(w);
     int *ctr = (int *)w; w += 256;              // ctr[0] = overflow count, ctr[1] = flags
@@ -611,7 +644,8 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     int nb = (int)((N + 255) / 256);
     hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(1024), 0, s, d2, mu, (int)N);
     hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, (const float *)mu, h1, qs, ctr + 1, g, 0);
-    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d2, (const float *)mu, h2, (float2 *)nullptr, ctr + 1, g, 1);
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((km_pad(max_cell_points(g)) + 255) / 256, g.ncx * g.ncy), dim3(256), 0, s, d2,
+                       (const float *)mu, h2, (float2 *)nullptr, ctr + 1, g, 1);
 
     KmGeom a;
     a.g = g; a.LP = p->label_pitch; a.tphi = p->tphi;
