@@ -8,7 +8,8 @@ df = pl.DiscreteFlow(H,W,seed=99)
 df.load_pair(img1,img2); df.generisi(); torch.cuda.synchronize()
 N=H*W
 def al(x): return (x+255)//256*256
-off = (2*N+1)*160 + N*8
+rows2 = 15*16*1728 + 16*2016   # image-2 rows in tile-position order, cells padded to 96 (knn_mfma.hip: km_total_rows)
+off = (N+rows2)*160 + N*8
 base = df.ws.data_ptr()
 off = al(base+off)-base
 ctr = df.ws[off:off+8].cpu().numpy().view(np.int32); print('ovf count, flags', ctr)
