@@ -51,7 +51,7 @@ typedef struct dflow_params {
     int32_t knn;                 /* daisy i flann.py:172  (5; kernels require 5) */
     int32_t window;              /* daisy i flann.py:167-168 (2 cells each side) */
     int32_t ngauss;              /* daisy i flann.py:207  (25) */
-    int32_t tpsi;                /* daisy i flann.py:47   (8)  */
+    int32_t tpsi;                /* daisy i flann.py:47   (8; kernels support 1..8) */
     int32_t max_attempts;        /* bound on draws per pixel in the neighbour sampler (65536) */
     float tphi;                  /* daisy i flann.py:46   (2.5) */
     float sigma;                 /* daisy i flann.py:208  (8)  */

@@ -40,7 +40,8 @@ int dflow_check_params(const dflow_params *p)
         return dflow_set_error(DFLOW_EINVAL, "maxnprop=%d must be in [%d,%d]", p->maxnprop, maxknn + p->ngauss, DFLOW_MAX_LABELS);
     if (p->label_pitch < p->maxnprop || p->label_pitch % 16 != 0 || p->label_pitch > DFLOW_MAX_LABELS)
         return dflow_set_error(DFLOW_EINVAL, "label_pitch=%d must be a multiple of 16 in [maxnprop,%d]", p->label_pitch, DFLOW_MAX_LABELS);
-    if (p->tpsi < 1 || p->tpsi > 4096) return dflow_set_error(DFLOW_EINVAL, "tpsi=%d outside [1,4096]", p->tpsi);
+    // pair costs below tpsi travel as 3-bit fields in the BCD label records (bcd.hip)
+    if (p->tpsi < 1 || p->tpsi > 8) return dflow_set_error(DFLOW_EINVAL, "tpsi=%d outside [1,8]", p->tpsi);
     if (!(p->sigma > 0.0f) || p->sigma > 8.0f) return dflow_set_error(DFLOW_EINVAL, "sigma=%g outside (0,8]", (double)p->sigma);
     if (p->max_attempts < p->ngauss) return dflow_set_error(DFLOW_EINVAL, "max_attempts < ngauss");
     return DFLOW_OK;

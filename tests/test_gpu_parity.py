@@ -350,6 +350,33 @@ def test_large_frame_invariants(torch_, oracle, synth):
     assert np.isfinite(flow).all() and np.abs(flow[..., 0]).max() <= 3 * g["ch"] + 25 and np.abs(flow[..., 1]).max() <= 3 * g["cw"] + 25
 
 
+@pytest.mark.parametrize("over", [dict(tpsi=5, tphi=1.5, lamda=0.1, ngauss=10, sigma=4.0),
+                                  dict(tpsi=1, tphi=0.75, lamda=1.0, ngauss=25, sigma=8.0, maxnprop=160),
+                                  dict(tpsi=8, tphi=2.5, lamda=0.05, ngauss=0, window=1)])
+def test_non_default_constants_match_oracle(torch_, oracle, synth, over):
+    """The module globals of the reference (tpsi, tphi, lamda, ngauss, sigma, maxnprop, window) are parameters of the ABI:
+    other values than the reference's go through the same kernels and must agree with the oracle stage by stage."""
+    O = oracle
+    H, W, ch, cw = 60, 84, 10, 12
+    img1, img2, _ = synth.make_pair(H, W, seed=99, amp_x=7.0, amp_y=5.0)
+    df = pkg("pipeline").DiscreteFlow(H, W, ch, cw, seed=21, **over)
+    p = O.make_params(H, W, ch, cw, seed=21, **over)
+    df.load_pair(img1, img2)
+    d1, d2 = O.daisy(img1), O.daisy(img2)
+    df.generisi()
+    pr, lc, npr, bl = O.knn_proposals(p, d1, d2)
+    df.nasumicni()
+    O.neighbour_proposals(p, d1, d2, pr, lc, npr, bl)
+    st = df.host_state()
+    assert np.array_equal(st["nprop"], npr) and np.array_equal(st["proposals"], pr) and np.array_equal(st["lcosts"], lc)
+    for sweep in range(2):
+        df.ceoBCD(1)
+        O.bcd_sweep(p, pr, lc, npr, bl)
+        assert np.array_equal(df.bestlabels.cpu().numpy(), bl), (over, sweep)
+    with pytest.raises(pkg("_lib").DflowError):
+        pkg("pipeline").DiscreteFlow(H, W, ch, cw, tpsi=9)
+
+
 def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
     """The two drop-in CLIs on a synthetic pair: file names, dtypes and contents as the reference writes them."""
     import runpy, sys, os
