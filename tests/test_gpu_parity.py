@@ -403,6 +403,12 @@ def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
         flo = pkg("flowio").read_flo("Gotova flow slika 106 backward=0 posle %02d BCD.flo" % w)
         assert np.array_equal(flo, f[..., ::-1].astype(np.float32))
     assert np.array_equal(np.load("Bestlabels fajl slike 106 backward=0 posle 02 BCD.npy"), ref["bestlabels"])
+    # dopython=0 (daisy i flann.py:423-426): pakovanjeZaC's four scan-order files instead of packedksets
+    monkeypatch.setattr(sys, "argv", ["daisy i flann.py", "6", "0", "0", "--synthetic", "%dx%d" % (H, W), "--cell", "%dx%d" % (ch, cw), "--seed", "11", "--packedksets"])
+    runpy.run_path(os.path.join(ROOT, PKG, "daisy i flann.py"), run_name="__main__")
+    for k, want in enumerate(pkg("compat").pakovani_za_c(pk)):
+        got = np.load("Daisy output slike 106 backward=0 pakovani za c %d.npy" % k)
+        assert got.dtype == np.uint8 and np.array_equal(got, want), k
 
 
 def test_batch_driver_config3(torch_, oracle, synth, tmp_path):
