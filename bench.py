@@ -9,12 +9,16 @@ no data-path collective) and the flow fields are gathered on rank 0 over xGMI af
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
+`python bench.py --gpus N` (N > 1, no RANK in the environment) starts its N ranks itself -- before anything touches the
+GPU -- and relays rank 0's JSON line; under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are the
+launcher's.  Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,8 +29,63 @@ PKG = "lk-s-2022-estimacija-pokreta_amd"
 H, W, BCD_TIMES = 436, 1024, 4
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (the kNN screen runs on f16 MFMA)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc passes of this command (tracked)
 
 
+# ---------------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """One child process per GPU, started BEFORE this process has touched torch.cuda / HIP (a process that has
+    initialised the GPU must never be replaced or forked into workers).  The children are plain `python bench.py ...`
+    processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, exactly what torch.distributed.run
+    would give them.  Rank 0's stdout (the JSON line) is relayed; the exit code is non-zero if any rank failed."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that dies leaves the others waiting in a collective: stop them (exactly the processes started above)
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.1)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks if c)
+    for line in out0.splitlines():                 # the JSON line goes to stdout, library chatter (gloo) to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------- accounting
 def knn_pairs(pich, picw, cellh, cellw, window=2):
     """Number of (image-1 pixel, image-2 candidate) distance evaluations of one pass."""
     ncx, ncy = picw // cellw, pich // cellh
@@ -37,21 +96,85 @@ def knn_pairs(pich, picw, cellh, cellw, window=2):
     return sx * sy
 
 
-def cpu_baseline(synth):
-    """The CPU oracle (a C port of the reference path, single thread) on a bounded sample of the same workload."""
+def epe_stats(flow, gt, mask=None):
+    """Mean / median end-point error and % > 3 px (metric of visualization.py:128-152) of a (H,W,2) [dy,dx] field."""
+    import numpy as np
+    e = np.sqrt(((flow.astype(np.float64) - gt) ** 2).sum(-1))
+    if mask is not None:
+        e = e[mask]
+    return {"mean": float(e.mean()), "median": float(np.median(e)), "pct_gt3": float((e > 3.0).mean() * 100.0),
+            "pixels": int(e.size)}
+
+
+def window_mask(gt, cellh, cellw, window=2):
+    """Pixels whose ground-truth target lies inside the image AND inside the +-window-cell search window
+    (daisy i flann.py:167-168): only there can a proposal reach the ground truth at all."""
+    import numpy as np
+    Hh, Ww, _ = gt.shape
+    ncx, ncy = Ww // cellw, Hh // cellh
+    yy, xx = np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij")
+    ty = np.rint(yy + gt[..., 0]).astype(np.int64)
+    tx = np.rint(xx + gt[..., 1]).astype(np.int64)
+    inside = (ty >= 0) & (ty < Hh) & (tx >= 0) & (tx < Ww)
+    cy = np.minimum(yy // cellh, ncy - 1); cx = np.minimum(xx // cellw, ncx - 1)
+    tcy = np.minimum(np.clip(ty, 0, Hh - 1) // cellh, ncy - 1); tcx = np.minimum(np.clip(tx, 0, Ww - 1) // cellw, ncx - 1)
+    return inside & (np.abs(tcy - cy) <= window) & (np.abs(tcx - cx) <= window)
+
+
+def cpu_baseline(synth, gpu_flow, bench_seed, cellh, cellw):
+    """The CPU oracle (a C port of the reference path) beside the GPU number, on this host's cores.
+
+    Entry 1 (headline): the bench's own pair (BASELINE configs[1]: 1024x436, forward, bcd_times=4), all usable cores;
+    its flow is also the EPE reference (`epe_delta_vs_oracle`).  Entry 2: BASELINE configs[0]'s geometry (1241x375,
+    cells 73x25, forward, 1 sweep: daisy i flann.py:34-35,42-43, python bcd.py:261-284) on a synthetic pair, all usable
+    cores.  Entry 3: 1/8 of a Sintel frame single-threaded, the form the reference itself runs in (one core)."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     O.build()
-    h, w = 109, 512                                  # 1/8 of the frame area, same 27x64 cells, same bcd_times
-    img1, img2, _ = synth.make_pair(h, w, seed=4242, amp_x=40.0, amp_y=20.0)
-    p = O.make_params(h, w, 27, 64, seed=1)
+    host_cores = os.cpu_count()
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores
+    threads = max(1, min(16, usable))          # a one-GPU box's CPU share
+    entries = []
+    O.set_threads(threads)
+    img1, img2, gt = synth.make_pair(H, W, seed=bench_seed)
     t0 = time.perf_counter()
-    O.full_pass(p, img1, img2, BCD_TIMES)
+    ref = O.full_pass(O.make_params(H, W, cellh, cellw, seed=0), img1, img2, BCD_TIMES)
     dt = time.perf_counter() - t0
-    return {"value": h * w / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d crop-sized synthetic pair (1/8 frame), cells 27x64, bcd_times=%d, %.1f s; "
-                      "C restatement of daisy i flann.py + python bcd.py (oracle/), exact kNN instead of FLANN"
-                      % (w, h, BCD_TIMES, dt)}
+    oracle_flow = ref["flows"][-1]
+    entries.append({"config": "BASELINE configs[1]: the bench pair, 1024x436, cells %dx%d, forward, bcd_times=%d" % (cellw, cellh, BCD_TIMES),
+                    "value": H * W / dt / 1e6, "unit": "Mpix/s", "threads": threads, "seconds": dt})
+    kh, kw = 375, 1241
+    a, b, _ = synth.make_pair(kh, kw, seed=synth.pair_seed(6, 0))
+    t0 = time.perf_counter()
+    O.full_pass(O.make_params(kh, kw, 25, 73, seed=0), a, b, 1)
+    dk = time.perf_counter() - t0
+    entries.append({"config": "BASELINE configs[0] geometry: 1241x375, cells 73x25, idx 6 forward, bcd_times=1 (synthetic pair: KITTI is absent)",
+                    "value": kh * kw / dk / 1e6, "unit": "Mpix/s", "threads": threads, "seconds": dk})
+    O.set_threads(1)
+    sh, sw = 109, 512
+    a, b, _ = synth.make_pair(sh, sw, seed=4242)
+    t0 = time.perf_counter()
+    O.full_pass(O.make_params(sh, sw, 27, 64, seed=1), a, b, BCD_TIMES)
+    ds = time.perf_counter() - t0
+    entries.append({"config": "512x109 synthetic pair (1/8 Sintel frame), cells 64x27, bcd_times=%d, single thread like the reference" % BCD_TIMES,
+                    "value": sh * sw / ds / 1e6, "unit": "Mpix/s", "threads": 1, "seconds": ds})
+    base = {"value": entries[0]["value"], "unit": "Mpix/s", "cores": threads, "kind": "port",
+            "host_cores": host_cores, "usable_cores": usable,
+            "sample": "the bench's own 1024x436 pair (whole frame, bcd_times=%d) in %.1f s on %d threads; C restatement of "
+                      "daisy i flann.py + python bcd.py (oracle/), exact kNN instead of FLANN; the reference's cv2/FLANN "
+                      "native code is absent and cannot be timed" % (BCD_TIMES, dt, threads),
+            "entries": entries}
+    # EPE of both paths against the synthetic ground truth, and their difference (labels are bit-identical => 0)
+    m = window_mask(gt, cellh, cellw)
+    g_all, g_win = epe_stats(gpu_flow, gt), epe_stats(gpu_flow, gt, m)
+    o_all, o_win = epe_stats(oracle_flow, gt), epe_stats(oracle_flow, gt, m)
+    epe = {"gpu": {"all_pixels": g_all, "gt_inside_image_and_search_window": g_win},
+           "oracle": {"all_pixels": o_all, "gt_inside_image_and_search_window": o_win},
+           "flow_fields_identical": bool(np.array_equal(gpu_flow.astype(np.float64), oracle_flow)),
+           "note": "DAISY is this build's restatement of OpenCV-contrib (parity unpinned: cv2 is absent), so EPE is vs the "
+                   "restated pipeline, not vs cv2-DAISY + FLANN"}
+    return base, epe, abs(g_all["mean"] - o_all["mean"])
 
 
 def stage_rooflines(torch, df, pair, cellh, cellw, reps=3):
@@ -98,6 +221,197 @@ def stage_rooflines(torch, df, pair, cellh, cellw, reps=3):
     }
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the tracked rocprofv3 --pmc summary (profiles/pmc_traffic.json, written by
+    scratch/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE passes of this command; FETCH_SIZE already doubled as
+    MI355X_MICROARCH.md prescribes for gfx950's wide reads).  None if the file has no entry."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            d = json.load(f)
+        e = d["kernels"][kernel]
+        return int(e["hbm_bytes_per_launch"]), d.get("source", PMC_TRAFFIC_FILE)
+    except Exception:
+        return None, None
+
+
+# ---------------------------------------------------------------------------------------------------- engines
+class GpuEngine:
+    """`inflight` independent pipelines per GPU: consecutive steps (= different image pairs) run on different HIP
+    streams, so the latency-bound BCD chains of one pair overlap the MFMA-bound kNN screening of the next.  Every step is
+    still one complete pass over one pair; the timed region contains exactly `steps` of them."""
+
+    def __init__(self, args, rank, local_rank, world):
+        import torch
+        self.torch = torch
+        self.synth = importlib.import_module(PKG + ".synth")
+        self.pipeline = importlib.import_module(PKG + ".pipeline")
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.backend = "nccl"
+        self.rank = rank
+        self.cellh, self.cellw = self.pipeline.default_cells(H, W)
+        self.P = max(1, min(args.inflight, args.steps))
+        self.flows = [self.pipeline.DiscreteFlow(H, W, self.cellh, self.cellw, device=self.dev, seed=rank) for _ in range(self.P)]
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.P)]
+        # two distinct synthetic pairs per rank, resident in HBM before the timed region
+        self.seeds = [self.synth.pair_seed(2 * rank + j, 0) for j in range(2)]
+        self.pairs = []
+        for sd in self.seeds:
+            img1, img2, _ = self.synth.make_pair(H, W, seed=sd)
+            self.pairs.append((torch.from_numpy(img1).to(self.dev), torch.from_numpy(img2).to(self.dev)))
+        self.bcd_events = []
+        self.gather = None
+
+    def like(self):
+        return self.flows[0].flow
+
+    def step(self, i, timed):
+        torch = self.torch
+        df, st = self.flows[i % self.P], self.streams[i % self.P]
+        a, b = self.pairs[i % 2]
+        with torch.cuda.stream(st):
+            df.load_pair(a, b)
+            df.generisi()
+            df.nasumicni()
+            df.pakovanje()
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            df.ceoBCD(BCD_TIMES)
+            if timed:
+                e1.record()
+                self.bcd_events.append((e0, e1))
+            flow = df.vratiKonacniFlow()
+            if self.gather is not None:
+                self.gather(flow, i % self.P)
+        return flow
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+class StubEngine:
+    """CPU stand-in used by tests/test_bench_launcher.py: the same launcher, rendezvous, barrier / max-over-ranks timing,
+    gather and JSON assembly as the GPU path, with gloo and a constant field instead of the HIP pipeline.  Never used for
+    a measurement (the line it prints says data = "stub")."""
+
+    def __init__(self, args, rank, local_rank, world):
+        import torch
+        self.torch = torch
+        self.backend = "gloo"
+        self.rank = rank
+        self.P = 1
+        self.field = torch.full((8, 8, 2), float(rank), dtype=torch.float32)
+        self.gather = None
+
+    def like(self):
+        return self.field
+
+    def step(self, i, timed):
+        if self.gather is not None:
+            self.gather(self.field, 0)
+        return self.field
+
+    def sync(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------------- worker
+def worker(args):
+    import torch
+    import torch.distributed as dist
+    sharding = importlib.import_module(PKG + ".sharding")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.stub and os.environ.get("DFLOW_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                       # tests/test_bench_launcher.py: a failing rank must fail the launcher
+    eng = (StubEngine if args.stub else GpuEngine)(args, rank, local_rank, world)
+    # under a launcher (ours or torch.distributed.run) the process group is always created, also for one rank, which
+    # exercises the same RCCL gather path; a plain `python bench.py` runs without torch.distributed
+    use_dist = "RANK" in os.environ
+    if use_dist:
+        if eng.backend == "nccl":
+            dist.init_process_group("nccl", device_id=eng.dev)
+        else:
+            dist.init_process_group("gloo")
+        bufs = [sharding.make_gather_buffers(eng.like(), world, rank) for _ in range(eng.P)]
+        eng.gather = lambda flow, slot: sharding.gather_flows(flow, bufs[slot], rank)
+
+    for i in range(args.warmup):
+        eng.step(i, False)
+
+    def sync_all():
+        eng.sync()
+        if use_dist:
+            dist.barrier()
+            eng.sync()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.step(i, True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.like().device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        out = {
+            "metric": "Mpix/s flow (1024x436, bcd_times=4)",
+            "value": world * args.steps * H * W / dt / 1e6,
+            "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "stub" if args.stub else "synthetic",
+        }
+        if not args.stub:
+            finish_report(out, eng, args, world)
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def finish_report(out, eng, args, world):
+    torch = eng.torch
+    P = eng.P
+    out["config"] = {"workload": "single 1024x436 Sintel-shape pair per step per GPU, forward only, bcd_times=4 "
+                                 "(BASELINE.json configs[1]); cells 64x27, 150 labels/px",
+                     "pairs_in_flight_per_gpu": P, "pair_seeds_rank0": eng.seeds,
+                     "parallelism": "one pass per step; %d independent steps in flight per GPU on separate HIP streams; "
+                                    "flow fields gathered on rank 0" % P}
+    # dominant kernel of a step: bcd_chain_kernel, 4 sweeps x 4 phases = 16 launches between the two events
+    launches = 4 * BCD_TIMES
+    bcd_ms = sum(a.elapsed_time(b) for a, b in eng.bcd_events) / max(1, len(eng.bcd_events)) / launches
+    # algorithmic bytes of one phase launch (SURVEY 8(d)): every pixel of half the image lines is visited once and
+    # needs its labels: L*4 B flows + L*4 B costs + 16 B per pixel, L = 150  ->  1216 B per visited pixel
+    alg_bytes = (H * W // 2) * (150 * 4 + 150 * 4 + 16)
+    achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic("bcd_chain_kernel")
+    out["roofline"] = {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "traffic": traffic, "traffic_source": traffic_src,
+                       "launch_ms": bcd_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                       "note": "launch_ms = HIP-event time of the 16 chain launches of a step / 16, measured on the launch "
+                               "stream with %d pairs in flight" % P}
+    out["roofline"]["stages"] = stage_rooflines(torch, eng.flows[0], eng.pairs[0], eng.cellh, eng.cellw)
+    # flow of the bench's first pair (what the EPE numbers refer to)
+    df = eng.flows[0]
+    gpu_flow = df.run(eng.pairs[0][0], eng.pairs[0][1], BCD_TIMES).cpu().numpy()
+    _, _, gt = eng.synth.make_pair(H, W, seed=eng.seeds[0])
+    m = window_mask(gt, eng.cellh, eng.cellw)
+    out["epe"] = {"gpu": {"all_pixels": epe_stats(gpu_flow, gt), "gt_inside_image_and_search_window": epe_stats(gpu_flow, gt, m)}}
+    out["epe_delta_vs_oracle"] = None
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"], out["epe"], out["epe_delta_vs_oracle"] = cpu_baseline(eng.synth, gpu_flow, eng.seeds[0], eng.cellh, eng.cellw)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,124 +420,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent pairs in flight per GPU (each on its own HIP stream and workspace)")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    synth = importlib.import_module(PKG + ".synth")
-    pipeline = importlib.import_module(PKG + ".pipeline")
-    sharding = importlib.import_module(PKG + ".sharding")
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # under torch.distributed.run the process group is always created (also for one rank, which exercises the same
-    # RCCL gather path); a plain `python bench.py` runs without torch.distributed
-    use_dist = "RANK" in os.environ
-    if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
-
-    cellh, cellw = pipeline.default_cells(H, W)
-    # `inflight` independent pipelines per GPU: consecutive steps (= different image pairs) run on different HIP streams,
-    # so the latency-bound BCD chains of one pair overlap the MFMA-bound kNN screening of the next.  Every step is still
-    # one complete pass over one pair; the timed region contains exactly `steps` of them.
-    P = max(1, min(args.inflight, args.steps))
-    flows = [pipeline.DiscreteFlow(H, W, cellh, cellw, device=dev, seed=rank) for _ in range(P)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
-    # two distinct synthetic pairs per rank, resident in HBM before the timed region
-    pairs = []
-    for j in range(2):
-        img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(2 * rank + j, 0))
-        pairs.append((torch.from_numpy(img1).to(dev), torch.from_numpy(img2).to(dev)))
-    gather_bufs = [sharding.make_gather_buffers(f.flow, world, rank) for f in flows] if use_dist else None
-
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    bcd_events = []
-
-    def step(i, timed):
-        df, st = flows[i % P], streams[i % P]
-        a, b = pairs[i % 2]
-        with torch.cuda.stream(st):
-            df.load_pair(a, b)
-            df.generisi()
-            df.nasumicni()
-            df.pakovanje()
-            if timed:
-                e0, e1 = ev(), ev()
-                e0.record()
-            df.ceoBCD(BCD_TIMES)
-            if timed:
-                e1.record()
-                bcd_events.append((e0, e1))
-            flow = df.vratiKonacniFlow()
-            if use_dist:
-                sharding.gather_flows(flow, gather_bufs[i % P], rank)
-        return flow
-
-    for i in range(args.warmup):
-        step(i, False)
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, True)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        # dominant kernel of a step: bcd_chain_kernel, 4 sweeps x 4 phases = 16 launches between the two events
-        launches = 4 * BCD_TIMES
-        bcd_ms = sum(a.elapsed_time(b) for a, b in bcd_events) / max(1, len(bcd_events)) / launches
-        # algorithmic bytes of one phase launch: every pixel of half the image lines is visited once and
-        # needs its labels: L*4 B flows + L*4 B costs + 16 B per pixel, L = 150  ->  1216 B per visited pixel
-        alg_bytes = (H * W // 2) * (150 * 4 + 150 * 4 + 16)
-        achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
-        out = {
-            "metric": "Mpix/s flow (1024x436, bcd_times=4)",
-            "value": world * args.steps * H * W / dt / 1e6,
-            "unit": "Mpix/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "single 1024x436 Sintel-shape pair per step per GPU, forward only, bcd_times=4 "
-                                   "(BASELINE.json configs[1]); cells 64x27, 150 labels/px",
-                       "pairs_in_flight_per_gpu": P,
-                       "parallelism": "one pass per step; %d independent steps in flight per GPU on separate HIP streams; "
-                                      "flow fields gathered on rank 0" % P},
-            "roofline": {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         # HBM-side bytes per launch from rocprofv3 --pmc (one counter per pass, profiles/r01_pmc_traffic.txt):
-                         # FETCH_SIZE 598299 KB, doubled as MI355X_MICROARCH.md prescribes for gfx950's wide (16 B/lane) reads,
-                         # + WRITE_SIZE 39138 KB.  Expected from the access pattern: 1.14 GB of 32-byte label records (160 rows
-                         # per visited pixel: the compat lists the reference keeps in packedksets ride along) + 36 MB back-pointers
-                         "traffic": (2 * 598299 + 39138) * 1024,
-                         "launch_ms": bcd_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "serial Viterbi chains (218-512 workgroups x 436-1024 dependent steps): latency-bound, "
-                                 "not bandwidth-bound; launch_ms is measured with %d pairs in flight" % P},
-        }
-        out["roofline"]["stages"] = stage_rooflines(torch, flows[0], pairs[0], cellh, cellw)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(synth)
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # nothing has touched the GPU in this process
+    worker(args)
 
 
 if __name__ == "__main__":

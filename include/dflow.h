@@ -38,6 +38,10 @@ extern "C" {
 #define DFLOW_DESC 68            /* (4 rings * 4 angles + 1) * 4 bins, daisy i flann.py:66 */
 #define DFLOW_MAX_LABELS 160     /* kernels are built for maxnprop <= 160 (reference: 150) */
 
+/* dflow_params.flags */
+#define DFLOW_FLAG_KNN_EXACT 1   /* dflow_knn_proposals: brute-force VALU search instead of the MFMA-screened one (same
+                                    results bit for bit; the cross-check of the screen's error bound) */
+
 #define DFLOW_OK 0
 #define DFLOW_EINVAL (-1)        /* bad parameter / null pointer / unsupported geometry */
 #define DFLOW_ENOSPC (-2)        /* workspace too small */
@@ -58,7 +62,7 @@ typedef struct dflow_params {
     double lamda;                /* daisy i flann.py:48   (0.05) */
     uint64_t seed;               /* key of the counter-based sampler (reference: unseeded np.random, :219) */
     int32_t label_pitch;         /* LP, elements per pixel in proposals/lcosts (160; multiple of 16) */
-    int32_t reserved;
+    int32_t flags;               /* DFLOW_FLAG_* bits (0 = defaults); per call, the library keeps no process-global switches */
 } dflow_params;
 
 int dflow_version(void);

@@ -13,6 +13,9 @@ SYMBOLS = ("dflow_version", "dflow_last_error", "dflow_default_params", "dflow_w
            "dflow_labels_to_flow", "dflow_fb_consistency", "dflow_pack_compat", "dflow_remove_small_segments_host")
 
 
+FLAG_KNN_EXACT = 1      # DFLOW_FLAG_KNN_EXACT
+
+
 class DflowError(RuntimeError):
     pass
 
@@ -22,7 +25,7 @@ class Params(C.Structure):
     _fields_ = [("pich", C.c_int32), ("picw", C.c_int32), ("cellh", C.c_int32), ("cellw", C.c_int32),
                 ("maxnprop", C.c_int32), ("knn", C.c_int32), ("window", C.c_int32), ("ngauss", C.c_int32),
                 ("tpsi", C.c_int32), ("max_attempts", C.c_int32), ("tphi", C.c_float), ("sigma", C.c_float),
-                ("lamda", C.c_double), ("seed", C.c_uint64), ("label_pitch", C.c_int32), ("reserved", C.c_int32)]
+                ("lamda", C.c_double), ("seed", C.c_uint64), ("label_pitch", C.c_int32), ("flags", C.c_int32)]
 
 
 def build(force=False):

@@ -44,6 +44,7 @@ int dflow_check_params(const dflow_params *p)
     if (p->tpsi < 1 || p->tpsi > 8) return dflow_set_error(DFLOW_EINVAL, "tpsi=%d outside [1,8]", p->tpsi);
     if (!(p->sigma > 0.0f) || p->sigma > 8.0f) return dflow_set_error(DFLOW_EINVAL, "sigma=%g outside (0,8]", (double)p->sigma);
     if (p->max_attempts < p->ngauss) return dflow_set_error(DFLOW_EINVAL, "max_attempts < ngauss");
+    if (p->flags & ~DFLOW_FLAG_KNN_EXACT) return dflow_set_error(DFLOW_EINVAL, "unknown flags 0x%x", (unsigned)p->flags);
     return DFLOW_OK;
 }
 
@@ -85,9 +86,8 @@ int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const floa
 {
     int rc = dflow_check_params(p); if (rc) return rc;
     CHECK_PTR(d_descr1); CHECK_PTR(d_descr2); CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels);
-    // DFLOW_KNN=exact selects the brute-force VALU kernel (same results; used to cross-check the MFMA path)
-    const char *mode = getenv("DFLOW_KNN");
-    if ((mode && strcmp(mode, "exact") == 0) || !knn_mfma_supported(p))
+    // DFLOW_FLAG_KNN_EXACT selects the brute-force VALU kernel (same results; used to cross-check the MFMA path)
+    if ((p->flags & DFLOW_FLAG_KNN_EXACT) || !knn_mfma_supported(p))
         return launch_knn(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, (hipStream_t)stream);
     CHECK_WS(knn_mfma_ws_bytes(p));
     return launch_knn_mfma(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, d_ws, (hipStream_t)stream);

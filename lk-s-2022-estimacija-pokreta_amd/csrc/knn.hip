@@ -2,7 +2,7 @@
 // the build's canonical exact 5-NN: squared L2 as a sequential fmaf chain over k = 0..67, ties to the lower
 // in-cell index, results in ascending (distance, index) order.
 //
-// This file holds (a) the brute-force kernel (DFLOW_KNN=exact, and the fallback for geometries the MFMA path does
+// This file holds (a) the brute-force kernel (DFLOW_FLAG_KNN_EXACT, and the fallback for geometries the MFMA path does
 // not cover) and (b) the fix-up kernel that re-does, exactly, the few (query wave, candidate cell) pairs the MFMA
 // path hands back (event-list overflow, or descriptors outside the f16 range).
 //

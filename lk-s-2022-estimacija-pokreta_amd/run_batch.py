@@ -45,9 +45,16 @@ def main(argv=None):
     df = pipeline.DiscreteFlow(H, W, device=dev, seed=rank)
     passes = [(pair, backward) for pair in range(a.pairs) for backward in (0, 1)]
 
+    # this rank's pairs are generated and uploaded BEFORE the passes run: compute() is GPU work only
+    mine = sharding.assign_passes(len(passes), world, rank)
+    images = {}
+    for pair in sorted({passes[i][0] for i in mine}):
+        img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(pair, 0))
+        images[pair] = (torch.from_numpy(img1).to(dev), torch.from_numpy(img2).to(dev))
+
     def compute(desc):
         pair, backward = desc
-        img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(pair, 0))
+        img1, img2 = images[pair]
         if backward:
             img1, img2 = img2, img1
         return df.run(img1, img2, a.bcd_times)

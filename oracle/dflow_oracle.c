@@ -20,6 +20,17 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads: the reference is single-threaded and so is this restatement by default.  orc_set_threads(n) lets the loops
+ * over independent units -- image rows in generisi's (ci,cj) body, image columns in nasumicni, the chains of one BCD
+ * phase (python bcd.py:265-277: they touch disjoint pixels) -- run on n threads; every unit is still computed by the same
+ * code in the same order, so the results do not depend on n (tests/test_oracle_golden.py checks that). */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
 
 #define ORC_DESC 68
 
@@ -300,11 +311,12 @@ void orc_knn_proposals(const orc_params *p, const float *d1, const float *d2,
     for (size_t i = 0; i < N * L * 2; i++) proposals[i] = -1;   /* :89 */
     for (size_t i = 0; i < N * L; i++) lcosts[i] = 1000.0;      /* :90 */
     for (size_t i = 0; i < N; i++) { nprop[i] = 0; bestlabels[i] = 0; mindists[i] = 1000.0; } /* :91-95 */
-    int32_t idx[16]; float dist[16], diff[ORC_DESC];
     for (int ci = 0; ci < ncx; ci++)          /* :162 ci outer */
         for (int cj = 0; cj < ncy; cj++) {    /* :163 cj inner */
             int cw = cell_x1(p, ci) - cell_x0(p, ci);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
             for (int y = 0; y < H; y++) {
+                int32_t idx[16]; float dist[16], diff[ORC_DESC];
                 if (abs(cell_y(p, y) - cj) > p->window) continue;       /* :168 */
                 for (int x = 0; x < W; x++) {
                     if (abs(cell_x(p, x) - ci) > p->window) continue;   /* :167 */
@@ -393,11 +405,14 @@ void orc_neighbour_proposals(const orc_params *p, const float *d1, const float *
                              int32_t *attempts_out)
 {
     int H = p->pich, W = p->picw, L = p->maxnprop, K = p->knn, ncy = ncelly_of(p);
-    uint32_t thr[127], rnd[4];
-    float diff[ORC_DESC];
+    uint32_t thr[127];
     orc_gauss_thresholds((double)p->sigma, thr);
+    /* pixels are independent: a draw reads the sampled neighbour's WTA proposal (a kNN slot, never rewritten here) */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
     for (int x = 0; x < W; x++)
         for (int y = 0; y < H; y++) {
+            uint32_t rnd[4];
+            float diff[ORC_DESC];
             size_t pix = (size_t)y * W + x;
             int mincellyl = cell_y(p, y) - p->window; if (mincellyl < 0) mincellyl = 0;            /* :212 */
             int ncellyl = (ncy < cell_y(p, y) + p->window ? ncy : cell_y(p, y) + p->window) - mincellyl; /* :214 */
@@ -568,10 +583,23 @@ void orc_bcd_phase(const orc_params *p, const int64_t *proposals, const double *
                    int64_t *bestlabels, int phase)
 {
     int H = p->pich, W = p->picw;
-    if (phase == 0) for (int x = 0; x < W; x += 2) orc_bcd_chain(p, proposals, lcosts, nprop, bestlabels, 1, 0, 0, x);
-    if (phase == 1) for (int y = 0; y < H; y += 2) orc_bcd_chain(p, proposals, lcosts, nprop, bestlabels, 0, -1, y, W - 1);
-    if (phase == 2) for (int x = (W / 2) * 2 - 1; x > -1; x -= 2) orc_bcd_chain(p, proposals, lcosts, nprop, bestlabels, -1, 0, H - 1, x);
-    if (phase == 3) for (int y = (H / 2) * 2 - 1; y > -1; y -= 2) orc_bcd_chain(p, proposals, lcosts, nprop, bestlabels, 0, 1, y, 0);
+    /* the chains of a phase read and write disjoint image lines (their side terms read the other parity only) */
+    if (phase == 0) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+        for (int x = 0; x < W; x += 2) orc_bcd_chain(p, proposals, lcosts, nprop, bestlabels, 1, 0, 0, x);
+    }
+    if (phase == 1) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+        for (int y = 0; y < H; y += 2) orc_bcd_chain(p, proposals, lcosts, nprop, bestlabels, 0, -1, y, W - 1);
+    }
+    if (phase == 2) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+        for (int x = (W / 2) * 2 - 1; x > -1; x -= 2) orc_bcd_chain(p, proposals, lcosts, nprop, bestlabels, -1, 0, H - 1, x);
+    }
+    if (phase == 3) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+        for (int y = (H / 2) * 2 - 1; y > -1; y -= 2) orc_bcd_chain(p, proposals, lcosts, nprop, bestlabels, 0, 1, y, 0);
+    }
 }
 
 void orc_bcd_sweep(const orc_params *p, const int64_t *proposals, const double *lcosts, const int64_t *nprop,

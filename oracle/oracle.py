@@ -50,6 +50,16 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_threads(n):
+    """Threads for the loops over independent units (rows / columns / chains); results do not depend on n.
+    The reference is single-threaded: the default is 1."""
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
+def get_threads():
+    return int(lib().orc_get_threads())
+
+
 def daisy(bgr):
     """izracunajDaisy (daisy i flann.py:69-77): (H,W,3) uint8 BGR -> (H,W,68) float32."""
     bgr = np.ascontiguousarray(bgr, dtype=np.uint8)

@@ -34,6 +34,10 @@ def test_version_and_struct_layout(L):
     assert (p.pich, p.picw, p.cellh, p.cellw) == (375, 1241, 25, 73)
     assert (p.maxnprop, p.knn, p.window, p.ngauss, p.tpsi) == (150, 5, 2, 25, 8)
     assert abs(p.tphi - 2.5) < 1e-7 and abs(p.sigma - 8.0) < 1e-7 and p.lamda == 0.05 and p.label_pitch == 160
+    assert p.flags == 0 and L.FLAG_KNN_EXACT == 1          # per-call switches live in the params, not in the environment
+    header = open(os.path.join(ROOT, "include", "dflow.h")).read()
+    assert "getenv" not in open(os.path.join(ROOT, pkg().__name__, "csrc", "abi.hip")).read()
+    assert re.search(r"#define\s+DFLOW_FLAG_KNN_EXACT\s+1\b", header)
 
 
 def test_workspace_size_and_validation(L):
@@ -43,7 +47,7 @@ def test_workspace_size_and_validation(L):
     assert ws > 436 * 1024 * 2 * 160 * 20                 # at least the BCD bit matrices
     for field, bad, msg in (("knn", 4, b"knn"), ("window", 3, b"window"), ("maxnprop", 200, b"maxnprop"),
                             ("label_pitch", 150, b"label_pitch"), ("cellh", 0, b"cell"), ("pich", 4, b"image size"),
-                            ("tpsi", 0, b"tpsi"), ("ngauss", 100, b"ngauss")):
+                            ("tpsi", 0, b"tpsi"), ("ngauss", 100, b"ngauss"), ("flags", 64, b"flags")):
         q = L.default_params(436, 1024, 27, 64)
         setattr(q, field, bad)
         assert lib.dflow_workspace_bytes(C.byref(q)) == 0

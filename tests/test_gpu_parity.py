@@ -10,6 +10,10 @@ from conftest import GOLDEN_NAMES, pkg
 pytestmark = pytest.mark.gpu
 
 # (H, W, cellh, cellw): exact tilings, ragged tilings (last cells absorb the remainder), more cells than the window
+# thresholds of test_bench_config_four_sweeps_match_oracle_and_epe (set from the measured values, see its docstring)
+EPE_REACHABLE_MEAN_MAX = 1.5
+EPE_REACHABLE_OUTLIER_PCT_MAX = 8.0
+
 GEOMS = [(40, 48, 5, 6), (36, 40, 9, 8), (45, 70, 7, 9), (96, 128, 12, 16), (64, 200, 10, 12)]
 
 
@@ -188,10 +192,92 @@ def test_full_size_sintel_properties_and_sampled_parity(torch_, oracle, synth):
     df.ceoBCD(1)
     O.bcd_sweep(p, pr, lc, npr, bl)
     assert np.array_equal(df.bestlabels.cpu().numpy(), bl)
-    # flow quality sanity: the discrete labels sit near the synthetic ground truth
-    flow = df.vratiKonacniFlow().cpu().numpy()
-    epe = np.sqrt(((flow - gt) ** 2).sum(-1))
-    assert np.median(epe) < 5.0
+
+
+def _window_mask(gt, ch, cw, window=2):
+    """Pixels whose ground-truth target lies inside the image and inside the +-2-cell search window (daisy i flann.py:167-168)."""
+    H, W, _ = gt.shape
+    ncx, ncy = W // cw, H // ch
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    ty = np.rint(yy + gt[..., 0]).astype(np.int64); tx = np.rint(xx + gt[..., 1]).astype(np.int64)
+    inside = (ty >= 0) & (ty < H) & (tx >= 0) & (tx < W)
+    cy = np.minimum(yy // ch, ncy - 1); cx = np.minimum(xx // cw, ncx - 1)
+    tcy = np.minimum(np.clip(ty, 0, H - 1) // ch, ncy - 1); tcx = np.minimum(np.clip(tx, 0, W - 1) // cw, ncx - 1)
+    return inside & (np.abs(tcy - cy) <= window) & (np.abs(tcx - cx) <= window)
+
+
+def test_full_frame_knn_mfma_equals_exact_at_bench_size(torch_, synth):
+    """BASELINE configs[1] geometry, every pixel: the MFMA-screened search and the brute-force kernel (DFLOW_FLAG_KNN_EXACT)
+    must agree on all of proposals, lcosts, nprop and bestlabels (446 464 x 125 exact 5-NN indices, bit for bit)."""
+    torch = torch_
+    H, W = 436, 1024
+    img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(0, 0))       # the bench's first pair
+    df = make(H, W, seed=0)
+    df.load_pair(img1, img2)
+    out = {}
+    for mode in (0, pkg("_lib").FLAG_KNN_EXACT):
+        df.p.flags = mode
+        df.generisi()
+        out[mode] = [t.clone() for t in (df.proposals, df.lcosts, df.nprop, df.bestlabels)]
+    df.p.flags = 0
+    for a, b, name in zip(out[0], out[pkg("_lib").FLAG_KNN_EXACT], ("proposals", "lcosts", "nprop", "bestlabels")):
+        assert torch.equal(a, b), name
+
+
+def test_bench_config_four_sweeps_match_oracle_and_epe(torch_, oracle, synth):
+    """BASELINE configs[1] exactly (1024x436, cells 64x27, bcd_times=4): labels after each of the 4 sweeps equal the oracle's
+    (run on the GPU's own proposals: the kNN stage has its own full-frame test above), and the end-point error against the
+    synthetic ground truth.  Thresholds: measured mean EPE 0.93 px / 4.4 % > 3 px over the pixels whose ground truth
+    is reachable (inside the image and the +-2-cell window), asserted with a 1.5x margin; over all pixels the unreachable
+    border band dominates (mean 3.7 px), which is a property of the search window, not of the build."""
+    H, W = 436, 1024
+    O = oracle
+    O.set_threads(16)
+    try:
+        img1, img2, gt = synth.make_pair(H, W, seed=synth.pair_seed(0, 0))
+        df = make(H, W, seed=0)
+        p = oracle_params(O, df)
+        df.load_pair(img1, img2)
+        df.generisi()
+        df.nasumicni()
+        st = df.host_state()
+        pr, lc, npr, bl = st["proposals"], st["lcosts"], st["nprop"], st["bestlabels"]
+        for w in range(4):
+            df.ceoBCD(1)
+            O.bcd_sweep(p, pr, lc, npr, bl)
+            assert np.array_equal(df.bestlabels.cpu().numpy(), bl), "sweep %d" % (w + 1)
+        flow = df.vratiKonacniFlow().cpu().numpy().astype(np.float64)
+        assert np.array_equal(flow, O.labels_to_flow(p, pr, bl))          # EPE delta vs the oracle is exactly 0
+        epe = np.sqrt(((flow - gt) ** 2).sum(-1))
+        m = _window_mask(gt, p.cellh, p.cellw)
+        print("EPE all: mean %.3f median %.3f >3px %.2f%% | reachable (%.1f%% of px): mean %.3f median %.3f >3px %.2f%%"
+              % (epe.mean(), np.median(epe), (epe > 3).mean() * 100, m.mean() * 100, epe[m].mean(), np.median(epe[m]), (epe[m] > 3).mean() * 100))
+        assert m.mean() > 0.5
+        assert epe[m].mean() < EPE_REACHABLE_MEAN_MAX and (epe[m] > 3).mean() * 100 < EPE_REACHABLE_OUTLIER_PCT_MAX
+    finally:
+        O.set_threads(1)
+
+
+def test_kitti_config5_eight_sweeps_match_oracle(torch_, oracle, synth):
+    """BASELINE configs[4] geometry and sweep count (1242x375, cells 54x25, bcd_times=8): labels after every sweep."""
+    H, W, ch, cw = 375, 1242, 25, 54
+    O = oracle
+    O.set_threads(16)
+    try:
+        img1, img2, _ = synth.make_pair(H, W, seed=H + W + 1)
+        df = make(H, W, ch, cw, seed=4)
+        p = oracle_params(O, df)
+        df.load_pair(img1, img2)
+        df.generisi()
+        df.nasumicni()
+        st = df.host_state()
+        pr, lc, npr, bl = st["proposals"], st["lcosts"], st["nprop"], st["bestlabels"]
+        for w in range(8):
+            df.ceoBCD(1)
+            O.bcd_sweep(p, pr, lc, npr, bl)
+            assert np.array_equal(df.bestlabels.cpu().numpy(), bl), "sweep %d" % (w + 1)
+    finally:
+        O.set_threads(1)
 
 
 @pytest.mark.parametrize("geom", [(375, 1241, 25, 73), (375, 1242, 25, 54)])
@@ -236,7 +322,7 @@ def test_kitti_geometries_sampled(torch_, oracle, synth, geom):
 
 
 def test_knn_mfma_path_equals_exact_kernel(torch_, synth, monkeypatch):
-    """The MFMA-screened search and the brute-force VALU kernel (DFLOW_KNN=exact) give identical outputs, also for
+    """The MFMA-screened search and the brute-force VALU kernel (DFLOW_FLAG_KNN_EXACT) give identical outputs, also for
     descriptors DAISY never produces (negative values) and where the screen has to hand the whole pass back to the exact
     fix-up kernel (values outside the f16 range, NaN-free)."""
     H, W, ch, cw = 96, 128, 12, 16
@@ -245,10 +331,7 @@ def test_knn_mfma_path_equals_exact_kernel(torch_, synth, monkeypatch):
     df.load_pair(img1, img2)
 
     def run(mode, d1, d2):
-        if mode:
-            monkeypatch.setenv("DFLOW_KNN", mode)
-        else:
-            monkeypatch.delenv("DFLOW_KNN", raising=False)
+        df.p.flags = pkg("_lib").FLAG_KNN_EXACT if mode else 0
         df.set_descriptors(d1, d2)
         df.generisi()
         return df.host_state()
@@ -296,10 +379,7 @@ def test_knn_mfma_screen_is_exact_on_hard_descriptors(torch_, synth, monkeypatch
         d1, d2 = d1 * m, d2 * m
 
     def run(mode):
-        if mode:
-            monkeypatch.setenv("DFLOW_KNN", mode)
-        else:
-            monkeypatch.delenv("DFLOW_KNN", raising=False)
+        df.p.flags = pkg("_lib").FLAG_KNN_EXACT if mode else 0
         df.set_descriptors(d1, d2)
         df.generisi()
         return df.host_state()
@@ -430,25 +510,30 @@ def test_batch_driver_config3(torch_, oracle, synth, tmp_path):
 
 
 def test_bench_contract(torch_, tmp_path):
-    """bench.py prints ONE JSON line with the driver's keys, the roofline object (dominant kernel + per-stage fractions) and
-    the CPU baseline; run as a child process, as the driver does."""
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object (dominant kernel + per-stage fractions), the
+    CPU baseline (whole bench pair on the host's cores + the configs[0] geometry + the single-thread sample) and the EPE of
+    the GPU flow and of the oracle's flow on the bench pair (difference exactly 0); run as a child process, as the driver does."""
     import json, os, subprocess, sys
     from conftest import ROOT
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+                         capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "epe", "epe_delta_vs_oracle"):
         assert k in d, k
     assert d["metric"].startswith("Mpix/s") and d["unit"] == "Mpix/s" and d["n_gpus"] == 1 and d["steps"] == 3
     assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 436 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["kernel"] == "bcd_chain_kernel" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1 and r["traffic"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0
     assert set(("daisy", "knn", "bcd", "end_to_end")) <= set(r["stages"])
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mpix/s" and 0 < c["value"] < d["value"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "Mpix/s" and 0 < c["value"] < d["value"]
+    assert len(c["entries"]) == 3 and c["entries"][2]["threads"] == 1 and "1241x375" in c["entries"][1]["config"]
+    assert d["epe_delta_vs_oracle"] == 0.0 and d["epe"]["flow_fields_identical"] is True
+    assert d["epe"]["gpu"]["all_pixels"] == d["epe"]["oracle"]["all_pixels"]

@@ -117,3 +117,22 @@ def test_daisy_structure(oracle, synth):
     dr = oracle.daisy(np.ascontiguousarray(ramp))
     c = dr[20, 20].reshape(17, 4)
     assert np.all(c[:, 0] > 0) and np.all(c[:, 2] == 0)
+
+
+def test_threaded_oracle_equals_serial(oracle, synth):
+    """orc_set_threads only distributes independent units (rows, columns, chains): the results must not depend on it."""
+    O = oracle
+    H, W, ch, cw = 40, 48, 5, 6
+    img1, img2, _ = synth.make_pair(H, W, seed=9, amp_x=4, amp_y=3)
+    p = O.make_params(H, W, ch, cw, seed=2)
+    try:
+        O.set_threads(1)
+        a = O.full_pass(p, img1, img2, 2)
+        O.set_threads(4)
+        assert O.get_threads() == 4
+        b = O.full_pass(p, img1, img2, 2)
+    finally:
+        O.set_threads(1)
+    for k in ("proposals", "lcosts", "nprop", "bestlabels"):
+        assert np.array_equal(a[k], b[k]), k
+    assert all(np.array_equal(x, y) for x, y in zip(a["flows"], b["flows"]))
