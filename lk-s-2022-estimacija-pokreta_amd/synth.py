@@ -1,9 +1,9 @@
 """Synthetic image pairs with known ground-truth flow: the reference reads KITTI PNGs from
 ../data_scene_flow (daisy i flann.py:26-27), which do not exist here, so tests and bench.py use these.
 
-img1: multi-octave smoothed noise texture, uint8 BGR.  gt: smooth flow, sum of low-frequency sinusoids,
-|u| <= amp_x, |v| <= amp_y (inside the +-2-cell search window).  img2(p + gt(p)) ~= img1(p): img2 is img1
-forward-mapped by the flow, realised as a backward warp with the (smooth) flow sampled at the target.
+img1: multi-octave smoothed noise texture, uint8 BGR.  g: smooth warp field, sum of low-frequency sinusoids,
+|gx| <= amp_x, |gy| <= amp_y (inside the +-2-cell search window).  img2(q) = img1(q - g(q)) (bilinear backward warp)
++ noise; the ground-truth flow of image 1's pixels is the fixed point f(p) = g(p + f(p)) (forward_gt).
 """
 import numpy as np
 
@@ -26,21 +26,47 @@ def _smooth_noise(rng, H, W, octaves=3):
     return acc
 
 
-def gt_flow(H, W, seed, amp_x=40.0, amp_y=20.0):
-    """(H,W,2) float64 [dy,dx] ground truth."""
+def _field(seed, amp_x, amp_y):
+    """The analytic warp field g(y, x) -> (gy, gx) in pixels of pair `seed`, y and x in units of the image size."""
     rng = np.random.default_rng(seed + 7919)
-    yy, xx = np.meshgrid(np.arange(H) / H, np.arange(W) / W, indexing="ij")
-    u = np.zeros((H, W)); v = np.zeros((H, W))
+    terms = []
     for k in range(3):
         fx, fy = rng.uniform(0.5, 2.0, 2)
         ph = rng.uniform(0, 2 * np.pi, 2)
-        u += np.sin(2 * np.pi * (fx * xx + fy * yy) + ph[0]) / 3.0
-        v += np.cos(2 * np.pi * (fy * xx - fx * yy) + ph[1]) / 3.0
-    return np.stack([amp_y * v, amp_x * u], axis=-1)
+        terms.append((fx, fy, ph[0], ph[1]))
+
+    def g(yn, xn):
+        u = np.zeros_like(xn, dtype=np.float64); v = np.zeros_like(xn, dtype=np.float64)
+        for fx, fy, p0, p1 in terms:
+            u = u + np.sin(2 * np.pi * (fx * xn + fy * yn) + p0) / 3.0
+            v = v + np.cos(2 * np.pi * (fy * xn - fx * yn) + p1) / 3.0
+        return amp_y * v, amp_x * u
+    return g
+
+
+def gt_flow(H, W, seed, amp_x=40.0, amp_y=20.0):
+    """(H,W,2) float64 [dy,dx]: the warp field sampled on the pixel grid of IMAGE 2 (img2(q) = img1(q - g(q)))."""
+    yy, xx = np.meshgrid(np.arange(H) / H, np.arange(W) / W, indexing="ij")
+    gy, gx = _field(seed, amp_x, amp_y)(yy, xx)
+    return np.stack([gy, gx], axis=-1)
+
+
+def forward_gt(H, W, seed, amp_x=40.0, amp_y=20.0, iters=60):
+    """(H,W,2) float64 [dy,dx]: the flow of IMAGE 1's pixels, i.e. what the hot path estimates.  img2 is a backward warp
+    (img2(q) = img1(q - g(q))), so pixel p of image 1 reappears at q = p + f(p) with f(p) = g(q): the fixed point of
+    f <- g(p + f), iterated on the analytic field (a contraction: |grad g| < 1 for the amplitudes used here).  Using g(p)
+    itself as ground truth is off by |grad g| * |g|, several pixels at 40 px amplitude."""
+    g = _field(seed, amp_x, amp_y)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    fy = np.zeros((H, W)); fx = np.zeros((H, W))
+    for _ in range(iters):
+        fy, fx = g((yy + fy) / H, (xx + fx) / W)
+    return np.stack([fy, fx], axis=-1)
 
 
 def make_pair(H, W, seed=0, amp_x=40.0, amp_y=20.0, noise=2.0):
-    """Returns (img1, img2, gt) with img uint8 (H,W,3) BGR and gt (H,W,2) float64 [dy,dx]."""
+    """Returns (img1, img2, gt) with img uint8 (H,W,3) BGR and gt (H,W,2) float64 [dy,dx] = forward_gt: the true flow of
+    image 1's pixels (where the warp leaves the image the field is still defined; the clipped source has no match there)."""
     rng = np.random.default_rng(seed)
     chans = [_smooth_noise(rng, H, W) for _ in range(3)]
     img1 = np.stack(chans, axis=-1) * 255.0
@@ -53,7 +79,7 @@ def make_pair(H, W, seed=0, amp_x=40.0, amp_y=20.0, noise=2.0):
             + fy * ((1 - fx) * img1[y0 + 1, x0] + fx * img1[y0 + 1, x0 + 1]))
     img2 = img2 + rng.normal(0.0, noise, img2.shape)
     to_u8 = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
-    return to_u8(img1), to_u8(img2), gt
+    return to_u8(img1), to_u8(img2), forward_gt(H, W, seed, amp_x, amp_y)
 
 
 def pair_seed(pair_idx, backward):

@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 
 # (H, W, cellh, cellw): exact tilings, ragged tilings (last cells absorb the remainder), more cells than the window
 # thresholds of test_bench_config_four_sweeps_match_oracle_and_epe (set from the measured values, see its docstring)
-EPE_REACHABLE_MEAN_MAX = 1.5
-EPE_REACHABLE_OUTLIER_PCT_MAX = 8.0
+EPE_REACHABLE_MEAN_MAX = 3.0
+EPE_REACHABLE_MEDIAN_MAX = 1.0
+EPE_REACHABLE_OUTLIER_PCT_MAX = 7.5
 
 GEOMS = [(40, 48, 5, 6), (36, 40, 9, 8), (45, 70, 7, 9), (96, 128, 12, 16), (64, 200, 10, 12)]
 
@@ -227,9 +228,12 @@ def test_full_frame_knn_mfma_equals_exact_at_bench_size(torch_, synth):
 def test_bench_config_four_sweeps_match_oracle_and_epe(torch_, oracle, synth):
     """BASELINE configs[1] exactly (1024x436, cells 64x27, bcd_times=4): labels after each of the 4 sweeps equal the oracle's
     (run on the GPU's own proposals: the kNN stage has its own full-frame test above), and the end-point error against the
-    synthetic ground truth.  Thresholds: measured mean EPE 0.93 px / 4.4 % > 3 px over the pixels whose ground truth
-    is reachable (inside the image and the +-2-cell window), asserted with a 1.5x margin; over all pixels the unreachable
-    border band dominates (mean 3.7 px), which is a property of the search window, not of the build."""
+    synthetic ground truth (synth.forward_gt: the true flow of image 1's pixels).  Measured on this pair after 4 sweeps, GPU and
+    oracle alike: over the pixels whose ground truth is reachable (target inside the image and the +-2-cell window, 96 % of
+    the frame) mean 2.41 px, median 0.81 px, 5.8 % > 3 px (sweep 0, WTA only: 30.4 / 1.06 / 32 %); over all pixels 4.83 /
+    0.84 / 8.6 % -- the unreachable border band is a property of the search window.  Thresholds = those values x 1.25.
+    (Round 1's "median 2.0 px" compared against the warp field sampled at the source pixel instead of the true forward
+    flow, an error of |grad g| |g| = several px in the ground truth itself; see synth.forward_gt.)"""
     H, W = 436, 1024
     O = oracle
     O.set_threads(16)
@@ -254,6 +258,7 @@ def test_bench_config_four_sweeps_match_oracle_and_epe(torch_, oracle, synth):
               % (epe.mean(), np.median(epe), (epe > 3).mean() * 100, m.mean() * 100, epe[m].mean(), np.median(epe[m]), (epe[m] > 3).mean() * 100))
         assert m.mean() > 0.5
         assert epe[m].mean() < EPE_REACHABLE_MEAN_MAX and (epe[m] > 3).mean() * 100 < EPE_REACHABLE_OUTLIER_PCT_MAX
+        assert np.median(epe[m]) < EPE_REACHABLE_MEDIAN_MAX
     finally:
         O.set_threads(1)
 
