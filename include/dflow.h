@@ -93,7 +93,7 @@ int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, cons
 
 /* Builds the compat bit matrices of pakovanje (daisy i flann.py:256-309) into the workspace, in the layout the chain
  * kernel reads: per pixel, per chain direction and per label one record with the compatible labels of the predecessor
- * on that chain, their pairwise costs, and the label's own flow and data cost (what ucitajSvePodatkeDoBCD,
+ * on that chain and their pairwise costs, plus per pixel every label's own flow and data cost (what ucitajSvePodatkeDoBCD,
  * python bcd.py:67-81, loads for bcd()).  Must be called after proposals and lcosts are final (after
  * dflow_neighbour_proposals / an upload) and before dflow_bcd_phase / dflow_bcd_sweep; the records stay valid until
  * another dflow_* stage call (daisy, knn) reuses the same workspace. */
@@ -110,6 +110,15 @@ int dflow_bcd_phase(const dflow_params *p, const uint32_t *d_proposals, const in
 /* One iteration of ceoBCD's loop (all four phases), python bcd.py:264-277. */
 int dflow_bcd_sweep(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_nprop,
                     int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream);
+
+/* The same loops for a BATCH of independent passes ((pair, direction) runs share nothing: README.md:40 of the reference)
+ * with identical parameters: the chains of all npass passes go into one launch, which fills the GPU where one pass
+ * alone (218-512 chains) cannot.  d_nprop / d_bestlabels / d_ws are HOST arrays of npass device pointers; every pass has its
+ * own workspace of ws_bytes, prepared by dflow_bcd_prepare.  Results are identical to npass separate calls. */
+int dflow_bcd_phase_batch(const dflow_params *p, int32_t npass, const int32_t *const *d_nprop, int32_t *const *d_bestlabels,
+                          int32_t phase, void *const *d_ws, size_t ws_bytes, void *stream);
+int dflow_bcd_sweep_batch(const dflow_params *p, int32_t npass, const int32_t *const *d_nprop, int32_t *const *d_bestlabels,
+                          void *const *d_ws, size_t ws_bytes, void *stream);
 
 /* vratiKonacniFlow, python bcd.py:90-95 / daisy i flann.py:192-197. */
 int dflow_labels_to_flow(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_bestlabels,

@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(CSRC, "libdflow.so")
 
 SYMBOLS = ("dflow_version", "dflow_last_error", "dflow_default_params", "dflow_workspace_bytes", "dflow_daisy",
            "dflow_knn_proposals", "dflow_neighbour_proposals", "dflow_bcd_prepare", "dflow_bcd_phase", "dflow_bcd_sweep",
+           "dflow_bcd_phase_batch", "dflow_bcd_sweep_batch",
            "dflow_labels_to_flow", "dflow_fb_consistency", "dflow_pack_compat", "dflow_remove_small_segments_host")
 
 
@@ -58,6 +59,8 @@ def lib():
         L.dflow_bcd_prepare.argtypes = [pp, vp, vp, vp, vp, sz, vp]
         L.dflow_bcd_phase.argtypes = [pp, vp, vp, vp, i32, vp, sz, vp]
         L.dflow_bcd_sweep.argtypes = [pp, vp, vp, vp, vp, sz, vp]
+        L.dflow_bcd_phase_batch.argtypes = [pp, i32, vp, vp, i32, vp, sz, vp]
+        L.dflow_bcd_sweep_batch.argtypes = [pp, i32, vp, vp, vp, sz, vp]
         L.dflow_labels_to_flow.argtypes = [pp, vp, vp, vp, vp]
         L.dflow_fb_consistency.argtypes = [pp, vp, vp, C.c_float, vp, vp]
         L.dflow_pack_compat.argtypes = [pp, vp, vp, vp, vp]

@@ -130,6 +130,29 @@ int dflow_bcd_sweep(const dflow_params *p, const uint32_t *d_proposals, const in
     return DFLOW_OK;
 }
 
+int dflow_bcd_phase_batch(const dflow_params *p, int32_t npass, const int32_t *const *d_nprop, int32_t *const *d_bestlabels,
+                          int32_t phase, void *const *d_ws, size_t ws_bytes, void *stream)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels); CHECK_PTR(d_ws);
+    if (npass < 1 || npass > 1024) return dflow_set_error(DFLOW_EINVAL, "npass=%d outside [1,1024]", npass);
+    if (phase < 0 || phase > 3) return dflow_set_error(DFLOW_EINVAL, "phase=%d outside [0,3]", phase);
+    if (ws_bytes < bcd_ws_bytes(p)) return dflow_set_error(DFLOW_ENOSPC, "%s: workspace %zu < %zu bytes", __func__, ws_bytes, bcd_ws_bytes(p));
+    for (int i = 0; i < npass; i++)
+        if (!d_nprop[i] || !d_bestlabels[i] || !d_ws[i]) return dflow_set_error(DFLOW_EINVAL, "%s: pass %d has a NULL pointer", __func__, i);
+    return launch_bcd_phase_batch(p, npass, d_nprop, d_bestlabels, phase, d_ws, (hipStream_t)stream);
+}
+
+int dflow_bcd_sweep_batch(const dflow_params *p, int32_t npass, const int32_t *const *d_nprop, int32_t *const *d_bestlabels,
+                          void *const *d_ws, size_t ws_bytes, void *stream)
+{
+    for (int ph = 0; ph < 4; ph++) {
+        int rc = dflow_bcd_phase_batch(p, npass, d_nprop, d_bestlabels, ph, d_ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DFLOW_OK;
+}
+
 int dflow_labels_to_flow(const dflow_params *p, const uint32_t *d_proposals, const int32_t *d_bestlabels, float *d_flow,
                          void *stream)
 {

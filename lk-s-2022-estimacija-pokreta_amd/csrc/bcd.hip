@@ -2,30 +2,42 @@
 // bit matrices (daisy i flann.py:256-309) in the orientation the chains need them.
 //
 // Two kernels:
-//   bcd_masks_kernel   once per pass (the proposals do not change during the sweeps): for every pixel p and both of
-//                      its chains (column chain / row chain) and every label tl of p, the set { k : tpsi > |dy-dy'|+|dx-dx'|
+//   bcd_lists_kernel   once per pass (the proposals do not change during the sweeps): for every pixel p, both of its
+//                      chains (column chain / row chain) and every label tl of p, the set { k : tpsi > |dy-dy'|+|dx-dx'|
 //                      between label tl of p and label k of p's predecessor on that chain } -- the reference's
 //                      packedksets (Q8), restricted to the two neighbours that are ever used and already transposed
 //                      for the direction in which the chain runs.  lanes = labels of p, the predecessor's labels are
 //                      wave-uniform: one v_sad_u16 + one v_alignbit per pair builds the 160-bit row in registers.  What
-//                      the chain kernel reads every step is a 32-byte record per row: the first 16 members as bytes,
-//                      their pairwise costs as nibbles, and the label's own flow and data cost.
-//   bcd_chain_kernel   one workgroup per chain of a phase (all chains of a phase are independent: a chain reads and
-//                      writes only its own image line).  192 threads, one per label; a lane walks its label's list
-//                      (only compatible predecessors cost float64 work), float64 arithmetic in the reference's
-//                      association order (dp = mincost + ((lamda*lcost + s1) + s2); first-index ties everywhere, Q9-Q11).
-//                      dp lives in LDS (double buffered), the records are prefetched three steps ahead, back-pointers
-//                      go to the workspace as uint8 and are walked chunk-wise from LDS.
+//                      the chain kernel streams is compact: per (pixel, direction, label) ONE 8-byte block with the first 5
+//                      members (index bytes + their pair costs) and the member count; labels with more than 5 (21 %) /
+//                      more than 10 (2.6 %) members own a second / third block, stored COMPACTED per 64-label wave (ballot
+//                      rank), so only the blocks that exist are ever fetched; rows with more than 15 members (0.2 %) keep
+//                      their 160-bit row.  Per pixel one 8-byte {biased flow, data cost} per label serves both directions.
+//   bcd_chain_kernel   one workgroup per (chain of a phase, pass of the batch): all chains of a phase are independent (a
+//                      chain reads and writes only its own image line), and so are the passes of a batch (README.md:40 of
+//                      the reference).  192 threads, one per label; a lane walks its label's list (only compatible
+//                      predecessors cost float64 work), float64 arithmetic in the reference's association order
+//                      (dp = mincost + ((lamda*lcost + s1) + s2); first-index ties everywhere, Q9-Q11).  dp lives in LDS
+//                      (double buffered), the blocks are prefetched four (first block, label data) and two (second and
+//                      third block) steps ahead, back-pointers go to the workspace as uint8 and are walked chunk-wise from
+//                      LDS.  17 KB of LDS and <= 80 VGPRs: eight workgroups per CU, so a batch of four passes is resident
+//                      at once and the kernel runs in a throughput regime (HBM streams of the blocks) instead of waiting
+//                      on one chain step at a time.
 #include "dflow_common.h"
 
 #define BCD_THREADS 192
-#define BCD_MASK_WORDS 5                 // 160 bits per label row (kept in HBM only for rows with more than 16 members)
-#define BCD_REC_WORDS 8                  // row record: 4 words = the first 16 members as bytes, increasing (0xFF = none);
-                                         // 2 words = their pairwise costs |dy-dy'|+|dx-dx'| (< tpsi <= 8) as nibbles, bit 63 =
-                                         // "more than 16 members"; 1 word = the label's biased flow; 1 word = its data cost
-#define BCD_LIST 16
+#define BCD_MASK_WORDS 5                 // 160 bits per label row (kept in HBM only for rows with more than 15 members)
+#define BCD_BLK 5                        // list members per 8-byte block
+#define BCD_LIST 15                      // members carried by blocks (3 blocks); longer rows continue in their bit row
 #define BCD_LDS_LABELS 256
-#define BCD_TB_STEPS 128                 // traceback chunk (steps) staged in LDS
+#define BCD_TB_STEPS 32                  // traceback chunk (steps) staged in LDS
+#define BCD_GROUPS 3                     // 64-label waves per pixel
+
+// 8-byte block: x = member indices k0..k3 (bytes, increasing, 0xFF = none: reads the +inf tail of dp);
+//               y = k4 | pair costs (nibble j = |dy-dy'|+|dx-dx'| < tpsi <= 8 of member j) << 8 | first block only:
+//                   bit 11 = "more than 15 members", bits 28..31 = min(count, 15)
+#define BLK_EMPTY_X 0xFFFFFFFFu
+#define BLK_EMPTY_Y 0x000000FFu
 
 __device__ static inline void chain_geom(int phase, int chain, int H, int W, int &ty, int &tx, int &ys, int &xs, int &len)
 {
@@ -36,11 +48,20 @@ __device__ static inline void chain_geom(int phase, int chain, int H, int W, int
     else { ty = (H / 2) * 2 - 1 - 2 * chain; tx = 0; ys = 0; xs = 1; len = W; }
 }
 
-// ------------------------------------------------------------------------------------------------ masks
+// workspace layout (all planes 256-byte aligned), shared by both kernels
+struct BcdPlanes {
+    uint8_t *back, *back_trash;      // back-pointers of the running phase [chain][step][LP] + a trash line
+    uint2 *lab;                      // [pix][LP]            {biased flow, data cost}
+    uint2 *blkA;                     // [pix][2][LP]         first block of every label
+    uint2 *blkB, *blkC;              // [pix][2][3][64]      second / third blocks, compacted per 64-label wave
+    uint32_t *masks;                 // [pix][2][LP][5]      160-bit rows (rows with more than 15 members only)
+};
+
+// ------------------------------------------------------------------------------------------------ lists
 // grid: one wave per (pixel, dir); dir 0 = the pixel's column chain, dir 1 = its row chain.
-__global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, int tpsi, const uint32_t *__restrict__ proposals,
+__global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, int tpsi, const uint32_t *__restrict__ proposals,
                                                         const float *__restrict__ lcosts, const int32_t *__restrict__ nprop,
-                                                        uint32_t *__restrict__ masks, uint32_t *__restrict__ recs)
+                                                        BcdPlanes pl)
 {
     __shared__ uint32_t s_cols[4][192];                      // the predecessor's biased labels, per wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -62,6 +83,13 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
         fp[j] = k < pn ? flow_bias(proposals[(size_t)ppix * LP + k]) : 0u;   // 0: far from every biased flow
         fcv[j] = k < tn ? flow_bias(proposals[(size_t)pix * LP + k]) : 0u;
         s_cols[wv][k] = fp[j];
+    }
+    if (dir == 0) {                                          // the pixel's label data, once (both directions read it)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int k = lane + 64 * j;
+            if (k < LP) pl.lab[(size_t)pix * LP + k] = make_uint2(fcv[j], __float_as_uint(k < tn ? lcosts[(size_t)pix * LP + k] : DFLOW_FILL_COST));
+        }
     }
     // lanes = labels of this pixel (three groups of 64), predecessor labels come one by one as wave-uniform scalars
     // (scalar loads of the predecessor's row): D = sad + (2^31 - tpsi) has bit 31 set iff the pair is NOT compatible,
@@ -87,20 +115,22 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
         }
     }
     const size_t rowbase = ((size_t)pix * 2 + dir) * (size_t)LP;
+    const size_t grpbase = ((size_t)pix * 2 + dir) * (size_t)(BCD_GROUPS * 64);
 #pragma unroll
     for (int grp = 0; grp < 3; grp++) {
         const int tl = 64 * grp + lane;
-        if (64 * grp >= tn) break;                           // wave-uniform
-        if (tl < tn) {
-            // the first 16 members as bytes and their pairwise costs as nibbles.  Both lists are shift registers filled
-            // from the top (position-independent inserts) and moved down to their final place afterwards.
-            uint32_t w[BCD_MASK_WORDS];
-            int cnt = 0;
+        if (64 * grp >= LP) break;                           // wave-uniform
+        // the first 15 members as bytes and their pairwise costs as nibbles.  Both lists are shift registers filled
+        // from the top (position-independent inserts) and moved down to their final place afterwards.  Labels beyond the
+        // pixel's count (and every label of a chain start) get an empty first block: the chain kernel reads all LP of them.
+        uint32_t w[BCD_MASK_WORDS];
+        int cnt = 0;
 #pragma unroll
-            for (int j = 0; j < BCD_MASK_WORDS; j++) { w[j] = ~m[grp][j]; cnt += __popc(w[j]); }
-            uint32_t l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu, l2 = 0xFFFFFFFFu, l3 = 0xFFFFFFFFu, p0 = 0u, p1 = 0u;
-            int n = 0;
-            const uint32_t me = fcv[grp];
+        for (int j = 0; j < BCD_MASK_WORDS; j++) { w[j] = tl < tn ? ~m[grp][j] : 0u; cnt += __popc(w[j]); }
+        uint32_t l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu, l2 = 0xFFFFFFFFu, l3 = 0xFFFFFFFFu, p0 = 0u, p1 = 0u;
+        int n = 0;
+        const uint32_t me = fcv[grp];
+        if (64 * grp < tn) {                                 // wave-uniform
 #pragma unroll
             for (int j = 0; j < BCD_MASK_WORDS; j++) {
                 uint32_t ww = w[j];
@@ -113,43 +143,54 @@ __global__ void __launch_bounds__(256) bcd_masks_kernel(int H, int W, int LP, in
                     n++;
                 }
             }
-            // n entries sit in the top n bytes / nibbles: shift right by 16-n places, 0xFF / 0 come in from the top
-            {
-                const int sh = BCD_LIST - n;                  // 0..16
-                if (sh & 1) { l0 = __builtin_amdgcn_alignbit(l1, l0, 8); l1 = __builtin_amdgcn_alignbit(l2, l1, 8);
-                              l2 = __builtin_amdgcn_alignbit(l3, l2, 8); l3 = __builtin_amdgcn_alignbit(0xFFFFFFFFu, l3, 8); }
-                if (sh & 2) { l0 = __builtin_amdgcn_alignbit(l1, l0, 16); l1 = __builtin_amdgcn_alignbit(l2, l1, 16);
-                              l2 = __builtin_amdgcn_alignbit(l3, l2, 16); l3 = __builtin_amdgcn_alignbit(0xFFFFFFFFu, l3, 16); }
-                if (sh & 4) { l0 = l1; l1 = l2; l2 = l3; l3 = 0xFFFFFFFFu; }
-                if (sh & 8) { l0 = l2; l1 = l3; l2 = 0xFFFFFFFFu; l3 = 0xFFFFFFFFu; }
-                if (sh & 16) { l0 = l1 = l2 = l3 = 0xFFFFFFFFu; }
-                unsigned long long pp = ((unsigned long long)p1 << 32) | p0;
-                pp = n ? pp >> (4 * sh) : 0ull;
-                p0 = (uint32_t)pp; p1 = (uint32_t)(pp >> 32);
-            }
-            if (cnt > BCD_LIST) p1 |= 0x80000000u;
-            uint32_t *rec = recs + (rowbase + tl) * BCD_REC_WORDS;
-            *reinterpret_cast<uint4 *>(rec) = make_uint4(l0, l1, l2, l3);
-            *reinterpret_cast<uint4 *>(rec + 4) = make_uint4(p0, p1, me, __float_as_uint(lcosts[(size_t)pix * LP + tl]));
-            if (cnt > BCD_LIST) {
-                // the 160-bit row itself: read by the chain kernel only for rows with more than 16 members
-                uint32_t *out = masks + (rowbase + tl) * BCD_MASK_WORDS;
+        }
+        // n entries sit in the top n bytes / nibbles: shift right by 16-n places, 0xFF / 0 come in from the top
+        {
+            const int sh = 16 - n;                            // 1..16
+            if (sh & 1) { l0 = __builtin_amdgcn_alignbit(l1, l0, 8); l1 = __builtin_amdgcn_alignbit(l2, l1, 8);
+                          l2 = __builtin_amdgcn_alignbit(l3, l2, 8); l3 = __builtin_amdgcn_alignbit(0xFFFFFFFFu, l3, 8); }
+            if (sh & 2) { l0 = __builtin_amdgcn_alignbit(l1, l0, 16); l1 = __builtin_amdgcn_alignbit(l2, l1, 16);
+                          l2 = __builtin_amdgcn_alignbit(l3, l2, 16); l3 = __builtin_amdgcn_alignbit(0xFFFFFFFFu, l3, 16); }
+            if (sh & 4) { l0 = l1; l1 = l2; l2 = l3; l3 = 0xFFFFFFFFu; }
+            if (sh & 8) { l0 = l2; l1 = l3; l2 = 0xFFFFFFFFu; l3 = 0xFFFFFFFFu; }
+            if (sh & 16) { l0 = l1 = l2 = l3 = 0xFFFFFFFFu; }
+            unsigned long long pp = ((unsigned long long)p1 << 32) | p0;
+            pp = n ? pp >> (4 * sh) : 0ull;
+            p0 = (uint32_t)pp; p1 = (uint32_t)(pp >> 32);
+        }
+        // bytes 0..3 | 4, 5..8 | 9, 10..13 | 14 and nibbles 0..4, 5..9, 10..14 -> the three blocks
+        const unsigned long long pp = ((unsigned long long)p1 << 32) | p0;
+        const uint32_t ax = l0;
+        const uint32_t ay = (l1 & 0xFFu) | (((uint32_t)pp & 0xFFFFFu) << 8) | (cnt > BCD_LIST ? 0x800u : 0u) | ((uint32_t)min(cnt, 15) << 28);
+        const uint32_t bx = __builtin_amdgcn_alignbit(l2, l1, 8);
+        const uint32_t by = ((l2 >> 8) & 0xFFu) | (((uint32_t)(pp >> 20) & 0xFFFFFu) << 8);
+        const uint32_t cx = __builtin_amdgcn_alignbit(l3, l2, 16);
+        const uint32_t cy = ((l3 >> 16) & 0xFFu) | (((uint32_t)(pp >> 40) & 0xFFFFFu) << 8);
+        if (tl < LP) pl.blkA[rowbase + tl] = make_uint2(ax, ay);
+        // second / third blocks: compacted per wave in lane order (rank = number of lower lanes that own one)
+        const unsigned long long hasB = __ballot(cnt > BCD_BLK), hasC = __ballot(cnt > 2 * BCD_BLK);
+        if (cnt > BCD_BLK) pl.blkB[grpbase + 64 * grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(hasB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasB, 0u))] = make_uint2(bx, by);
+        if (cnt > 2 * BCD_BLK) pl.blkC[grpbase + 64 * grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(hasC >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasC, 0u))] = make_uint2(cx, cy);
+        if (cnt > BCD_LIST) {
+            // the 160-bit row itself: read by the chain kernel only for rows with more than 15 members
+            uint32_t *out = pl.masks + (rowbase + tl) * BCD_MASK_WORDS;
 #pragma unroll
-                for (int j = 0; j < BCD_MASK_WORDS; j++) out[j] = w[j];
-            }
+            for (int j = 0; j < BCD_MASK_WORDS; j++) out[j] = w[j];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ chains
+#define BCD_MAX_BATCH 8
+struct BcdPass {
+    const int32_t *nprop;
+    int32_t *bestlabels;
+    BcdPlanes pl;
+};
 struct BcdArgs {
     int H, W, LP, tpsi, phase;
     double lamda;
-    const uint32_t *proposals;
-    const int32_t *nprop;
-    int32_t *bestlabels;
-    const uint32_t *masks, *recs;
-    uint8_t *back, *back_trash;
+    BcdPass pass[BCD_MAX_BATCH];
 };
 
 struct Cand {
@@ -196,7 +237,6 @@ __device__ static inline void wave_min_lane0(Cand &pm)
     }
 }
 
-
 // Minimum of a 64-bit key over the wave (keys = bit patterns of positive doubles, which order like the doubles) and the
 // first lane that attains it: high words first, then the low words of the lanes that tie on the high word.
 // minimum of a 32-bit value over the wave, wave-uniform result: 4 fused DPP minima inside the rows of 16 lanes (lanes
@@ -238,27 +278,16 @@ __device__ static inline unsigned long long wave_key_min_asm(unsigned long long 
 
 template <int V> struct IntC { static constexpr int value = V; };
 
-#ifdef BCD_PROF
-// diagnostic build only (scratch/): per-wave cycle stamps of the step sections of block 0, summed over the chain
-__device__ unsigned long long g_bcd_prof[3][8];
-extern "C" void dflow_debug_bcd_prof(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bcd_prof), sizeof(g_bcd_prof)); }
-extern "C" void dflow_debug_bcd_prof_reset() { unsigned long long z[24] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bcd_prof), z, sizeof(z)); }
-#define PROF_DECL unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt = 0;
-#define PROF_START pt = __builtin_amdgcn_s_memtime();
-#define PROF(k) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc[k] += n_ - pt; pt = n_; }
-#else
-#define PROF_DECL
-#define PROF_START
-#define PROF(k)
-#endif
+__device__ static inline uint32_t lane_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 
-// One thread per label: 192 threads (3 waves) cover up to DFLOW_MAX_LABELS labels.  Few, busy threads keep the
-// per-step instruction count low: every wave is alone on its SIMD, so a step costs (instructions x issue cycles).
-__global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
+// One thread per label: 192 threads (3 waves) cover up to DFLOW_MAX_LABELS labels.
+__global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
 {
     // static LDS has compile-time addresses, so the offsets fold into the ds_read immediates
     __shared__ double s_dp[2 * BCD_LDS_LABELS];                               // [2][labels]; entries >= 160 stay +inf (list sentinel 0xFF)
-    __shared__ uint32_t s_fp[2 * BCD_LDS_LABELS];                             // [2][labels] biased flows (rows with more than 16 members only)
     __shared__ unsigned long long permv[2 * 4];                               // per-wave minima of bits(tpsi + dp)
     __shared__ int permi[2 * 4 + 4];                                          // their labels; [8] = traceback hand-over
     __shared__ __attribute__((aligned(16))) uint8_t tb[BCD_TB_STEPS * DFLOW_MAX_LABELS];   // traceback chunk
@@ -268,10 +297,12 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     int *s_label = permi + 8;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tl = tid < DFLOW_MAX_LABELS ? tid : DFLOW_MAX_LABELS - 1;   // threads 160..191 shadow the last label row and never write
-    const bool owner = tid < DFLOW_MAX_LABELS;
     const int chain = blockIdx.x;
+    const BcdPass &ps = a.pass[blockIdx.y];
+    const BcdPlanes &pl = ps.pl;
     const int W = a.W, LP = a.LP;
+    const bool owner = tid < LP;                       // threads LP..191 shadow the last label row and never write
+    const int tl = owner ? tid : LP - 1;
     int ty0, tx0, ys, xs, len;
     chain_geom(a.phase, chain, a.H, W, ty0, tx0, ys, xs, len);
     const int pstep = ys * W + xs;            // pixel-index step along the chain
@@ -284,83 +315,91 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     const double tpsi_d = (double)a.tpsi;
 
     tnl = (int *)(bestf + len + 1);
-    for (int i = tid; i < 2 * BCD_LDS_LABELS; i += BCD_THREADS) { s_dp[i] = 1e300; s_fp[i] = 0u; }
+    for (int i = tid; i < 2 * BCD_LDS_LABELS; i += BCD_THREADS) s_dp[i] = 1e300;
     for (int i = tid; i < len; i += BCD_THREADS) {
         int pix = pix0 + i * pstep;
-        bestf[i] = flow_bias(a.proposals[(size_t)pix * LP + a.bestlabels[pix]]);
-        tnl[i] = a.nprop[pix];      // a wave-uniform global load inside the step loop would stall every step (it is
+        bestf[i] = pl.lab[(size_t)pix * LP + ps.bestlabels[pix]].x;
+        tnl[i] = ps.nprop[pix];     // a wave-uniform global load inside the step loop would stall every step (it is
                                     // moved to an SGPR at once); the label counts are read from LDS instead
     }
     if (tid == 0) { bestf[-1] = 0u; bestf[len] = 0u; }       // read, never used (the limit of that side term is 0)
     __syncthreads();
 
-    // Per-step inputs of this thread = its label's 32-byte record (see BCD_REC_WORDS), prefetched three steps ahead.
-    // All loads are unconditional (rows are LP wide; records of unused labels hold garbage that indexes inside the LDS
-    // arrays and is never written back), so nothing in a step waits for a load issued in the same step.
-    struct StepIn { uint4 rl; uint4 px; };   // rl = byte list; px = {cost nibbles lo, hi | more flag, biased flow, data cost}
-    const uint32_t offr = (uint32_t)tl * (BCD_REC_WORDS * 4u);
-    const size_t rowbytesr = (size_t)LP * (BCD_REC_WORDS * 4u);
-    auto fetch = [&](int i) {
-        StepIn r;
-        const size_t pix = (size_t)(pix0 + min(i, len - 1) * pstep);
-        const char *pr = (const char *)a.recs + (pix * 2 + dir) * rowbytesr;
-        r.rl = *reinterpret_cast<const uint4 *>(pr + offr);
-        r.px = *reinterpret_cast<const uint4 *>(pr + offr + 16);
-        return r;
+    // Per-step inputs of this thread: its label's first block and label data, prefetched four steps ahead into four
+    // static register slots, and its second / third block (if it owns one: the first block's count says so), fetched two
+    // steps ahead.  Rows are LP wide and every first block is initialised, so the first-block and label loads are
+    // unconditional; nothing in a step waits for a load issued in the same step.
+    const uint32_t offl = (uint32_t)tl * 8u;
+    const size_t rowl = (size_t)LP * 8u, rowg = (size_t)(BCD_GROUPS * 64) * 8u;
+    auto pixof = [&](int i) { return (size_t)(pix0 + min(i, len - 1) * pstep); };
+    auto fetchA = [&](int i) { return *reinterpret_cast<const uint2 *>((const char *)pl.blkA + (pixof(i) * 2 + dir) * rowl + offl); };
+    auto fetchL = [&](int i) { return *reinterpret_cast<const uint2 *>((const char *)pl.lab + pixof(i) * rowl + offl); };
+    // second / third block of step i, given that step's first block: lanes that own none keep the empty block
+    auto fetchBC = [&](int i, const uint2 &blkA, uint2 &B, uint2 &C) {
+        const uint32_t cnt = blkA.y >> 28;
+        const bool hb = owner && cnt > BCD_BLK, hc = owner && cnt > 2 * BCD_BLK;
+        const unsigned long long mb = __ballot(hb);
+        B = make_uint2(BLK_EMPTY_X, BLK_EMPTY_Y); C = make_uint2(BLK_EMPTY_X, BLK_EMPTY_Y);
+        if (mb) {                                                     // wave-uniform
+            const char *gb = (const char *)pl.blkB + (pixof(i) * 2 + dir) * rowg + (size_t)wave * 512u;
+            if (hb) B = *reinterpret_cast<const uint2 *>(gb + lane_rank(mb) * 8u);
+            const unsigned long long mc = __ballot(hc);
+            if (mc) {
+                const char *gc = (const char *)pl.blkC + (pixof(i) * 2 + dir) * rowg + (size_t)wave * 512u;
+                if (hc) C = *reinterpret_cast<const uint2 *>(gc + lane_rank(mc) * 8u);
+            }
+        }
     };
-    const StepIn S0 = fetch(0);
-    StepIn A = fetch(1), B = fetch(2), C = fetch(3);
+    uint2 A0, L0 = fetchL(0);
+    uint2 A1 = fetchA(1), L1 = fetchL(1), A2 = fetchA(2), L2 = fetchL(2), A3 = fetchA(3), L3 = fetchL(3);
+    uint2 B1, C1, B0, C0;
+    fetchBC(1, A1, B1, C1);
+    fetchBC(2, A2, B0, C0);
 
     // ---- chain start: dp[0,tl] = (s1 + s2) + lamda*lcost   (python bcd.py:118-120)
     {
-        const uint32_t Fc = S0.px.z;
+        const uint32_t Fc = L0.x;
         const int ip = dirp, im = -dirp;
         const uint32_t s1 = (ip >= 0 && ip < len) ? min(tpsi, flow_l1_biased(Fc, bestf[ip])) : 0u;
         const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
         unsigned long long key = ~0ull;
         if (owner && tl < tnl[0]) {
-            const double d0 = __dadd_rn((double)(s1 + s2), __dmul_rn(a.lamda, (double)__uint_as_float(S0.px.w)));
+            const double d0 = __dadd_rn((double)(s1 + s2), __dmul_rn(a.lamda, (double)__uint_as_float(L0.y)));
             s_dp[tl] = d0;
-            s_fp[tl] = Fc;
             key = (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, d0));
         }
         int fl;
         const unsigned long long m = wave_key_min_asm(key, &fl);
         if (lane == 0) { permv[wave] = m; permi[wave] = wave * 64 + fl; }
     }
+    A0 = fetchA(4); L0 = fetchL(4);
     __syncthreads();
 
-    PROF_DECL
     int pn = tnl[0];
-    uint8_t *backp = owner ? a.back + (size_t)chain * len * LP + tl : a.back_trash + (tid - DFLOW_MAX_LABELS);   // + i*LP per step
+    uint8_t *backp = owner ? pl.back + ((size_t)blockIdx.x * len) * LP + tl : pl.back_trash + (tid - LP);   // + i*LP per step
     const uint32_t bstride = owner ? (uint32_t)LP : 0u;
-    // One step of the chain; CUR (compile-time) is the LDS buffer this step writes, CUR^1 holds the previous pixel.  `in`
-    // is consumed first and then refilled with the record of step i+3: the three slots are used round-robin by the 6x
-    // unrolled loop below, so prefetched registers are never copied while their loads are still in flight (a register
-    // rotation A=B, B=C would make every step wait for the loads it has just issued).  The common path of a step is one
-    // basic block (the wave is alone on its SIMD: every wave-uniform branch costs more than a few wasted instructions).
-    auto step = [&](auto curc, const int i, StepIn &in) __attribute__((always_inline)) {
+    // One step of the chain; CUR (compile-time) is the LDS buffer this step writes, CUR^1 holds the previous pixel.
+    // (inA, inL) = this step's first block and label data, refilled with those of step i+4; (inB, inC) = this step's
+    // second / third blocks, refilled with those of step i+2, whose first block `nxA` arrived two steps ago.  The slots
+    // are used round-robin by the 4x unrolled loop below, so prefetched registers are never copied while their loads
+    // are still in flight.
+    auto step = [&](auto curc, const int i, uint2 &inA, uint2 &inL, uint2 &inB, uint2 &inC, const uint2 &nxA) __attribute__((always_inline)) {
         constexpr int CUR = decltype(curc)::value;
         const char *prev = reinterpret_cast<const char *>(s_dp + (CUR ^ 1) * BCD_LDS_LABELS);
-        const uint32_t *fprev = s_fp + (CUR ^ 1) * BCD_LDS_LABELS;
-        PROF_START
         const int tn = tnl[i];
-        const uint4 rl = in.rl;
-        const uint32_t pw0 = in.px.x, pw1 = in.px.y, Fc = in.px.z;
-        const float lc = __uint_as_float(in.px.w);
+        const uint32_t ax = inA.x, ay = inA.y, bx = inB.x, by = inB.y, cx = inC.x, cy = inC.y;
+        const uint32_t Fc = inL.x;
+        const float lc = __uint_as_float(inL.y);
         const bool act = owner && tl < tn;
-        in = fetch(i + 3);
-        PROF(0)
+        inA = fetchA(i + 4); inL = fetchL(i + 4);
+        fetchBC(i + 2, nxA, inB, inC);
         // min over compatible previous labels (python bcd.py:163-176 / :198-219) in increasing k (strict '<' keeps the
-        // first minimum).  The first 16 compatible predecessors of every row come as a byte list in increasing k (0xFF =
-        // none, which reads the +inf tail of dp) together with their pair costs; the LDS reads of the first 12 are issued
-        // at once (most waves need 9 to 12; a wave-uniform exit after 8 costs as much as it saves).  Candidates are
-        // tracked by their dp offset 8 k.
-        uint32_t ad[12]; double dd[12];
+        // first minimum).  Members come as index bytes in increasing k (0xFF = none, which reads the +inf tail of dp)
+        // with their pair costs; candidates are tracked by their dp offset 8 k.
+        uint32_t ad[BCD_BLK]; double dd[BCD_BLK];
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const uint32_t w = j < 4 ? rl.x : (j < 8 ? rl.y : rl.z);
-            ad[j] = ((w >> (8 * (j & 3))) & 0xFFu) << 3;
+        for (int j = 0; j < BCD_BLK; j++) {
+            ad[j] = ((j < 4 ? ax >> (8 * j) : ay) & 0xFFu) << 3;
             dd[j] = *reinterpret_cast<const double *>(prev + ad[j]);
         }
         // permmincost / permminlabel (python bcd.py:152-157) merged from the per-wave partials of the previous step (waves
@@ -381,45 +420,51 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
             perm.v = __longlong_as_double((long long)pmn); perm.k = pix_;
             small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
         }
-        PROF(1)
         double bestv = 1e300; uint32_t besta = 0x7fffffffu;
-        {
 #pragma unroll
-            for (int j = 0; j < 12; j++) {
-                const double c = __dadd_rn(dd[j], (double)(((j < 8 ? pw0 : pw1) >> (4 * (j & 7))) & 7u));
-                const bool t = c < bestv;               // +inf + psi = +inf never wins
-                bestv = __builtin_fmin(bestv, c); besta = t ? ad[j] : besta;
+        for (int j = 0; j < BCD_BLK; j++) {
+            const double c = __dadd_rn(dd[j], (double)((ay >> (8 + 4 * j)) & 7u));
+            const bool t = c < bestv;               // +inf + psi = +inf never wins
+            bestv = __builtin_fmin(bestv, c); besta = t ? ad[j] : besta;
+        }
+        // second block: some label of the wave has more than 5 members (almost always true for a full wave)
+        if (__ballot(act && (ay >> 28) > BCD_BLK) != 0ull) {
+            uint32_t a2[BCD_BLK]; double d2[BCD_BLK];
+#pragma unroll
+            for (int j = 0; j < BCD_BLK; j++) { a2[j] = ((j < 4 ? bx >> (8 * j) : by) & 0xFFu) << 3; d2[j] = *reinterpret_cast<const double *>(prev + a2[j]); }
+#pragma unroll
+            for (int j = 0; j < BCD_BLK; j++) {
+                const double c = __dadd_rn(d2[j], (double)((by >> (8 + 4 * j)) & 7u));
+                const bool t = c < bestv;
+                bestv = __builtin_fmin(bestv, c); besta = t ? a2[j] : besta;
             }
-            PROF(2)
-            // few rows have more than 12 members (wave-uniform branch on the longest row of the wave), fewer still more than 16
-            if (__builtin_expect(__ballot(act && (rl.w & 0xFFu) != 0xFFu) != 0ull, 0)) {
-                {
-                    uint32_t a4[4]; double d4[4];
+            // third block (a quarter of the waves), rows beyond 15 members (2 % of the workgroup steps)
+            if (__builtin_expect(__ballot(act && (ay >> 28) > 2 * BCD_BLK) != 0ull, 0)) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { a4[j] = ((rl.w >> (8 * j)) & 0xFFu) << 3; d4[j] = *reinterpret_cast<const double *>(prev + a4[j]); }
+                for (int j = 0; j < BCD_BLK; j++) { a2[j] = ((j < 4 ? cx >> (8 * j) : cy) & 0xFFu) << 3; d2[j] = *reinterpret_cast<const double *>(prev + a2[j]); }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const double c = __dadd_rn(d4[j], (double)((pw1 >> (4 * (4 + j))) & 7u));
-                        const bool t = c < bestv;
-                        bestv = __builtin_fmin(bestv, c); besta = t ? a4[j] : besta;
-                    }
+                for (int j = 0; j < BCD_BLK; j++) {
+                    const double c = __dadd_rn(d2[j], (double)((cy >> (8 + 4 * j)) & 7u));
+                    const bool t = c < bestv;
+                    bestv = __builtin_fmin(bestv, c); besta = t ? a2[j] : besta;
                 }
-                PROF(3)
-                const bool more16 = act && (int)pw1 < 0;
-                if (__builtin_expect(__ballot(more16) != 0ull, 0)) {
-                    // some rows are denser still: those lanes fetch their 160-bit row and walk what is left behind the 16th
-                    // list entry, four set bits per round; still increasing k, so strict '<' stands
-                    const int k15 = (int)(rl.w >> 24);
-                    const size_t rowidx = ((size_t)(pix0 + i * pstep) * 2 + dir) * LP + tl;
-                    const uint32_t *mrow = a.masks + rowidx * BCD_MASK_WORDS;
+                const bool more = act && (ay & 0x800u) != 0u;
+                if (__builtin_expect(__ballot(more) != 0ull, 0)) {
+                    // denser rows still: those lanes fetch their 160-bit row and walk what is left behind the 15th list
+                    // member, four set bits per round; still increasing k, so strict '<' stands.  The predecessor's
+                    // flows come from its label data (this path is rare; everything it reads is L2-resident)
+                    const int k14 = (int)(cy & 0xFFu);
+                    const size_t cpix = (size_t)(pix0 + i * pstep), ppix = (size_t)(pix0 + (i - 1) * pstep);
+                    const uint32_t *mrow = pl.masks + ((cpix * 2 + dir) * LP + tl) * BCD_MASK_WORDS;
+                    const uint2 *plab = pl.lab + ppix * LP;
                     unsigned long long w0 = 0, w1 = 0, w2 = 0;
-                    if (more16) {
+                    if (more) {
                         w0 = (unsigned long long)mrow[0] | ((unsigned long long)mrow[1] << 32);
                         w1 = (unsigned long long)mrow[2] | ((unsigned long long)mrow[3] << 32);
                         w2 = (unsigned long long)mrow[4];
-                        const int b = k15 & 63;
+                        const int b = k14 & 63;
                         const unsigned long long keep = b == 63 ? 0ull : (~0ull << (b + 1));
-                        if (k15 < 64) w0 &= keep; else if (k15 < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
+                        if (k14 < 64) w0 &= keep; else if (k14 < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
                     }
                     int base = 0;
                     auto next_bit = [&](bool &valid) {
@@ -434,7 +479,7 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
 #pragma unroll
                         for (int j = 0; j < 4; j++) kk[j] = next_bit(v[j]);
 #pragma unroll
-                        for (int j = 0; j < 4; j++) { d4[j] = *reinterpret_cast<const double *>(prev + 8 * kk[j]); ff[j] = fprev[kk[j]]; }   // invalid slots read label 0: harmless
+                        for (int j = 0; j < 4; j++) { d4[j] = *reinterpret_cast<const double *>(prev + 8 * kk[j]); ff[j] = plab[kk[j]].x; }   // invalid slots read label 0: harmless
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             const double c = __dadd_rn(d4[j], (double)flow_l1_biased(Fc, ff[j]));
@@ -445,53 +490,42 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
                 }
             }
         }
-        PROF(4)
-        // No branch on `act`: the slots of labels beyond this pixel's count (dp, flow, back-pointer) may hold anything, no
+        // No branch on `act`: the slots of labels beyond this pixel's count (dp, back-pointer) may hold anything, no
         // list and no traceback refers to them; the shadow lanes (tid >= 160) write to LDS slots 160..191 (equally
         // unreferenced) and to a trash line behind the back-pointer array.
         unsigned long long key;
         {
             const bool found = besta != 0x7fffffffu;
             const double mincost = found ? bestv : perm.v;
-            const int pl = found ? (int)(besta >> 3) : perm.k;
+            const int pl_ = found ? (int)(besta >> 3) : perm.k;
             const double dpc = __dadd_rn(mincost, small);
             s_dp[CUR * BCD_LDS_LABELS + tid] = dpc;
-            s_fp[CUR * BCD_LDS_LABELS + tid] = Fc;
-            backp[(size_t)i * bstride] = (uint8_t)pl;
+            backp[(size_t)i * bstride] = (uint8_t)pl_;
             key = act ? (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, dpc)) : ~0ull;
         }
-        PROF(5)
         {
             int fl;
             const unsigned long long m = wave_key_min_asm(key, &fl);
             if (lane == 0) { permv[CUR * 4 + wave] = m; permi[CUR * 4 + wave] = wave * 64 + fl; }
         }
-        PROF(6)
         // LDS-only barrier: __syncthreads() would also wait for the global prefetches issued in this step (vmcnt(0)) and
         // put their full latency on every step of the chain
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        PROF(7)
         pn = tn;
     };
+    // step i: first block / label slot i mod 4, second / third block slot i mod 2, next-next first block = slot (i+2) mod 4
     int i = 1;
-    for (; i + 5 < len; i += 6) {                       // whole groups of six without per-step bounds checks
-        step(IntC<1>(), i, A);
-        step(IntC<0>(), i + 1, B);
-        step(IntC<1>(), i + 2, C);
-        step(IntC<0>(), i + 3, A);
-        step(IntC<1>(), i + 4, B);
-        step(IntC<0>(), i + 5, C);
+    for (; i + 3 < len; i += 4) {                       // whole groups of four without per-step bounds checks
+        step(IntC<1>(), i, A1, L1, B1, C1, A3);
+        step(IntC<0>(), i + 1, A2, L2, B0, C0, A0);
+        step(IntC<1>(), i + 2, A3, L3, B1, C1, A1);
+        step(IntC<0>(), i + 3, A0, L0, B0, C0, A2);
     }
-    if (i < len) step(IntC<1>(), i, A);
-    if (i + 1 < len) step(IntC<0>(), i + 1, B);
-    if (i + 2 < len) step(IntC<1>(), i + 2, C);
-    if (i + 3 < len) step(IntC<0>(), i + 3, A);
-    if (i + 4 < len) step(IntC<1>(), i + 4, B);
-#ifdef BCD_PROF
-    if (blockIdx.x == 7 && lane == 0) for (int k = 0; k < 8; k++) g_bcd_prof[wave][k] += pacc[k];
-#endif
+    if (i < len) step(IntC<1>(), i, A1, L1, B1, C1, A3);
+    if (i + 1 < len) step(IntC<0>(), i + 1, A2, L2, B0, C0, A0);
+    if (i + 2 < len) step(IntC<1>(), i + 2, A3, L3, B1, C1, A1);
     const int cur = (len & 1) ? 1 : 0;         // the buffer the step after the last one would write; the last written is cur^1
 
     // ---- end label: first minimum of dp[len-1] (python bcd.py:231-237): tpsi + dp is monotone in dp, but two different
@@ -505,9 +539,9 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
     }
     __syncthreads();
     // ---- traceback (python bcd.py:239-253): chunks of back-pointer rows are staged in LDS, one thread walks them
-    uint8_t *back = a.back + (size_t)chain * len * LP;
-    int pl = *s_label;
-    if (tid == 0) a.bestlabels[pix0 + (len - 1) * pstep] = pl;
+    uint8_t *back = pl.back + ((size_t)blockIdx.x * len) * LP;
+    int plb = *s_label;
+    if (tid == 0) ps.bestlabels[pix0 + (len - 1) * pstep] = plb;
     for (int hi = len - 1; hi >= 1; hi -= BCD_TB_STEPS) {
         const int lo = max(1, hi - BCD_TB_STEPS + 1);      // steps lo..hi
         const int nbytes = (hi - lo + 1) * LP;
@@ -515,14 +549,14 @@ __global__ void __launch_bounds__(BCD_THREADS) bcd_chain_kernel(BcdArgs a)
         for (int j = tid; j < nbytes / 16; j += BCD_THREADS) reinterpret_cast<uint4 *>(tb)[j] = src[j];
         __syncthreads();
         if (tid == 0) {
-            for (int i = hi; i >= lo; i--) {
-                pl = tb[(i - lo) * LP + pl];
-                a.bestlabels[pix0 + (i - 1) * pstep] = pl;
+            for (int i2 = hi; i2 >= lo; i2--) {
+                plb = tb[(i2 - lo) * LP + plb];
+                ps.bestlabels[pix0 + (i2 - 1) * pstep] = plb;
             }
-            *s_label = pl;
+            *s_label = plb;
         }
         __syncthreads();
-        pl = *s_label;
+        plb = *s_label;
     }
 }
 
@@ -535,6 +569,8 @@ static void phase_dims(const dflow_params *p, int phase, int &nchains, int &len)
     else { nchains = H / 2; len = W; }
 }
 
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 static size_t back_bytes(const dflow_params *p)
 {
     size_t m = 0;
@@ -544,44 +580,67 @@ static size_t back_bytes(const dflow_params *p)
         size_t b = (size_t)n * len * p->label_pitch;
         if (b > m) m = b;
     }
-    return ((m + 255) & ~(size_t)255) + 256;      // + a trash line for the shadow lanes of the chain kernel
+    return align256(m) + 256;      // + a trash line for the shadow lanes of the chain kernel
 }
 
+static size_t lab_bytes(const dflow_params *p) { return align256((size_t)p->pich * p->picw * p->label_pitch * 8); }
+static size_t blka_bytes(const dflow_params *p) { return align256((size_t)p->pich * p->picw * 2 * p->label_pitch * 8); }
+static size_t blkg_bytes(const dflow_params *p) { return align256((size_t)p->pich * p->picw * 2 * (BCD_GROUPS * 64) * 8); }
 static size_t mask_bytes(const dflow_params *p)
 {
-    return (size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_MASK_WORDS * sizeof(uint32_t);
+    return align256((size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_MASK_WORDS * sizeof(uint32_t));
 }
 
-static size_t rec_bytes(const dflow_params *p)
+size_t bcd_ws_bytes(const dflow_params *p) { return back_bytes(p) + lab_bytes(p) + blka_bytes(p) + 2 * blkg_bytes(p) + mask_bytes(p); }
+
+static BcdPlanes planes_of(const dflow_params *p, void *ws)
 {
-    return (size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_REC_WORDS * sizeof(uint32_t);
+    BcdPlanes pl;
+    char *w = (char *)ws;
+    pl.back = (uint8_t *)w; pl.back_trash = (uint8_t *)w + back_bytes(p) - 256; w += back_bytes(p);
+    pl.lab = (uint2 *)w; w += lab_bytes(p);
+    pl.blkA = (uint2 *)w; w += blka_bytes(p);
+    pl.blkB = (uint2 *)w; w += blkg_bytes(p);
+    pl.blkC = (uint2 *)w; w += blkg_bytes(p);
+    pl.masks = (uint32_t *)w;
+    return pl;
 }
-
-size_t bcd_ws_bytes(const dflow_params *p) { return back_bytes(p) + mask_bytes(p) + rec_bytes(p); }
 
 int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop, void *ws,
                        hipStream_t s)
 {
-    uint32_t *masks = (uint32_t *)((char *)ws + back_bytes(p));
-    uint32_t *recs = (uint32_t *)((char *)ws + back_bytes(p) + mask_bytes(p));
     long long items = 2LL * p->pich * p->picw;
-    hipLaunchKernelGGL(bcd_masks_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p->pich, p->picw, p->label_pitch,
-                       p->tpsi, proposals, lcosts, nprop, masks, recs);
-    return dflow_check_launch("bcd_masks_kernel");
+    hipLaunchKernelGGL(bcd_lists_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p->pich, p->picw, p->label_pitch,
+                       p->tpsi, proposals, lcosts, nprop, planes_of(p, ws));
+    return dflow_check_launch("bcd_lists_kernel");
+}
+
+int launch_bcd_phase_batch(const dflow_params *p, int npass, const int32_t *const *nprop, int32_t *const *bestlabels, int phase,
+                           void *const *ws, hipStream_t s)
+{
+    int nchains, len;
+    phase_dims(p, phase, nchains, len);
+    if (nchains == 0) return DFLOW_OK;
+    size_t shmem = (size_t)(len + 2) * sizeof(uint32_t) + (size_t)len * sizeof(int);
+    for (int b0 = 0; b0 < npass; b0 += BCD_MAX_BATCH) {
+        const int nb = npass - b0 < BCD_MAX_BATCH ? npass - b0 : BCD_MAX_BATCH;
+        BcdArgs a;
+        a.H = p->pich; a.W = p->picw; a.LP = p->label_pitch; a.tpsi = p->tpsi; a.phase = phase; a.lamda = p->lamda;
+        for (int b = 0; b < BCD_MAX_BATCH; b++) {
+            const int src = b0 + (b < nb ? b : 0);
+            a.pass[b].nprop = nprop[src]; a.pass[b].bestlabels = bestlabels[src]; a.pass[b].pl = planes_of(p, ws[src]);
+        }
+        hipLaunchKernelGGL(bcd_chain_kernel, dim3(nchains, nb), dim3(BCD_THREADS), shmem, s, a);
+        int rc = dflow_check_launch("bcd_chain_kernel");
+        if (rc) return rc;
+    }
+    return DFLOW_OK;
 }
 
 int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, int32_t *bestlabels, int phase,
                      void *ws, hipStream_t s)
 {
-    int nchains, len;
-    phase_dims(p, phase, nchains, len);
-    if (nchains == 0) return DFLOW_OK;
-    BcdArgs a;
-    a.H = p->pich; a.W = p->picw; a.LP = p->label_pitch; a.tpsi = p->tpsi; a.phase = phase; a.lamda = p->lamda;
-    a.proposals = proposals; a.nprop = nprop; a.bestlabels = bestlabels;
-    a.back = (uint8_t *)ws; a.back_trash = (uint8_t *)ws + back_bytes(p) - 256; a.masks = (const uint32_t *)((char *)ws + back_bytes(p));
-    a.recs = (const uint32_t *)((char *)ws + back_bytes(p) + mask_bytes(p));
-    size_t shmem = (size_t)(len + 2) * sizeof(uint32_t) + (size_t)len * sizeof(int);
-    hipLaunchKernelGGL(bcd_chain_kernel, dim3(nchains), dim3(BCD_THREADS), shmem, s, a);
-    return dflow_check_launch("bcd_chain_kernel");
+    (void)proposals;
+    void *wsv = ws;
+    return launch_bcd_phase_batch(p, 1, &nprop, &bestlabels, phase, &wsv, s);
 }

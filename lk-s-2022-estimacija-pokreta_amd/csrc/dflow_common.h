@@ -98,6 +98,8 @@ int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, ui
                      int32_t *nprop, const int32_t *bestlabels, hipStream_t s);
 int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, int32_t *bestlabels, int phase,
                      void *ws, hipStream_t s);
+int launch_bcd_phase_batch(const dflow_params *p, int npass, const int32_t *const *nprop, int32_t *const *bestlabels, int phase,
+                           void *const *ws, hipStream_t s);
 size_t bcd_ws_bytes(const dflow_params *p);
 int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop, void *ws,
                        hipStream_t s);

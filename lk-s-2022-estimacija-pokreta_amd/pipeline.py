@@ -175,6 +175,34 @@ class DiscreteFlow:
         self._bcd_ready = False
 
 
+def ceoBCD_batch(passes, bcd_times, on_sweep=None):
+    """ceoBCD (python bcd.py:261-284) for several independent passes at once (forward and backward runs of a pair, several
+    pairs: README.md:40 of the reference): the chains of all passes share the four launches of a sweep.  `passes` are
+    DiscreteFlow objects of identical geometry and constants on one device; results equal separate ceoBCD calls."""
+    passes = list(passes)
+    if not passes:
+        return
+    first = passes[0]
+    for df in passes:
+        if bytes(df.p) != bytes(first.p) and (df.p.pich, df.p.picw, df.p.cellh, df.p.cellw, df.p.tpsi, df.p.lamda, df.p.label_pitch, df.p.maxnprop) != \
+                (first.p.pich, first.p.picw, first.p.cellh, first.p.cellw, first.p.tpsi, first.p.lamda, first.p.label_pitch, first.p.maxnprop):
+            raise ValueError("batched passes must share geometry and constants")
+        if df.device != first.device:
+            raise ValueError("batched passes must live on one device")
+        if not df._bcd_ready:
+            df.pakovanje()
+    n = len(passes)
+    arr = C.c_void_p * n
+    nprop = arr(*[df.nprop.data_ptr() for df in passes])
+    best = arr(*[df.bestlabels.data_ptr() for df in passes])
+    ws = arr(*[df.ws.data_ptr() for df in passes])
+    for w in range(1, bcd_times + 1):
+        _lib.check(_lib.lib().dflow_bcd_sweep_batch(first._pp(), n, nprop, best, ws, first.ws_bytes, first._stream()),
+                   "dflow_bcd_sweep_batch")
+        if on_sweep is not None:
+            on_sweep(w)
+
+
 def fb_consistency(fwd, bwd, tresh, p=None):
     """postProcessing (postprocessing.py:123-135) on two (H,W,2) [dy,dx] float32 device tensors ->
     (H,W,3) float32 [U,V,valid] device tensor."""

@@ -140,6 +140,27 @@ def test_bcd_from_uploaded_reference_state(torch_, oracle, synth):
         assert np.array_equal(df.bestlabels.cpu().numpy(), bl)
 
 
+@pytest.mark.parametrize("geom", [(45, 70, 7, 9), (96, 128, 12, 16)])
+def test_batched_sweeps_equal_separate_sweeps(torch_, oracle, synth, geom):
+    """dflow_bcd_sweep_batch: the chains of several independent passes (forward and backward run of two pairs) in one
+    launch per phase give the labels of separate calls, which are the oracle's."""
+    H, W, ch, cw = geom
+    O = oracle
+    pl = pkg("pipeline")
+    passes, refs = [], []
+    for k in range(5):                      # 5 passes: forward/backward of pair 0 and 1, forward of pair 2
+        img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(k // 2, 0), amp_x=0.08 * W, amp_y=0.08 * H)
+        if k % 2:
+            img1, img2 = img2, img1
+        df = make(H, W, ch, cw, seed=k)
+        df.load_pair(img1, img2); df.generisi(); df.nasumicni()
+        passes.append(df)
+        refs.append(O.full_pass(O.make_params(H, W, ch, cw, seed=k), img1, img2, 3)["bestlabels"])
+    pl.ceoBCD_batch(passes, 3)
+    for k, df in enumerate(passes):
+        assert np.array_equal(df.bestlabels.cpu().numpy(), refs[k]), "pass %d" % k
+
+
 def test_full_size_sintel_properties_and_sampled_parity(torch_, oracle, synth):
     """BASELINE config 2 geometry (1024x436, 64x27 cells, ragged last cell row).  The oracle cannot run the whole
     kNN here in reasonable time, so: exact comparison on sampled (pixel, cell) searches, full comparison of the
