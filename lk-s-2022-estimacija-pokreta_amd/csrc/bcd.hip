@@ -50,7 +50,7 @@ __device__ static inline void chain_geom(int phase, int chain, int H, int W, int
 
 // workspace layout (all planes 256-byte aligned), shared by both kernels
 struct BcdPlanes {
-    uint8_t *back, *back_trash;      // back-pointers of the running phase [chain][step][LP] + a trash line
+    uint8_t *back;                   // back-pointers of the running phase [chain][step][192 threads]
     uint2 *lab;                      // [pix][LP]            {biased flow, data cost}
     uint2 *blkA;                     // [pix][2][LP]         first block of every label
     uint2 *blkB, *blkC;              // [pix][2][3][64]      second / third blocks, compacted per 64-label wave
@@ -284,24 +284,36 @@ __device__ static inline uint32_t lane_rank(unsigned long long mask)
 }
 
 // One thread per label: 192 threads (3 waves) cover up to DFLOW_MAX_LABELS labels.
+#define BCD_BACK_PITCH BCD_THREADS       // back-pointer rows: one byte per THREAD (no special case for the shadow lanes)
+
+typedef const __attribute__((address_space(1))) char *gptr_t;      // a pointer known to be global memory (not flat)
+__device__ static inline gptr_t uniform_ptr(const void *p)
+{
+    // tells the compiler that the pointer is wave-uniform (it is: kernel arguments and block indices only) and global, so
+    // that the loads below use the scalar-base + 32-bit lane offset form and the row pointers advance with scalar adds
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gptr_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ static inline unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
 {
     // static LDS has compile-time addresses, so the offsets fold into the ds_read immediates
     __shared__ double s_dp[2 * BCD_LDS_LABELS];                               // [2][labels]; entries >= 160 stay +inf (list sentinel 0xFF)
     __shared__ unsigned long long permv[2 * 4];                               // per-wave minima of bits(tpsi + dp)
     __shared__ int permi[2 * 4 + 4];                                          // their labels; [8] = traceback hand-over
-    __shared__ __attribute__((aligned(16))) uint8_t tb[BCD_TB_STEPS * DFLOW_MAX_LABELS];   // traceback chunk
+    __shared__ __attribute__((aligned(16))) uint8_t tb[BCD_TB_STEPS * BCD_BACK_PITCH];   // traceback chunk
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     uint32_t *bestf = s_dyn + 1;                                      // [-1..len] biased flow of each chain pixel's current label
     int *tnl;                                                         // [len] nprop of each chain pixel (set below)
     int *s_label = permi + 8;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chain = blockIdx.x;
-    const BcdPass &ps = a.pass[blockIdx.y];
-    const BcdPlanes &pl = ps.pl;
     const int W = a.W, LP = a.LP;
-    const bool owner = tid < LP;                       // threads LP..191 shadow the last label row and never write
+    const bool owner = tid < LP;                       // threads LP..191 shadow the last label row; nothing refers to what they compute
+    const unsigned long long ownmask = ballot64(owner);
     const int tl = owner ? tid : LP - 1;
     int ty0, tx0, ys, xs, len;
     chain_geom(a.phase, chain, a.H, W, ty0, tx0, ys, xs, len);
@@ -313,48 +325,67 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
     const int dirp = ys + xs;                 // +1 if the chain runs towards larger coordinates, else -1
     const uint32_t tpsi = (uint32_t)a.tpsi;
     const double tpsi_d = (double)a.tpsi;
+    const double lamda = a.lamda;
+    // this pass's planes (copied out of the argument block once: nothing below reloads kernel arguments)
+    const BcdPass &ps = a.pass[blockIdx.y];
+    const int32_t *g_nprop = ps.nprop;
+    int32_t *g_best = ps.bestlabels;
+    const uint2 *g_lab = ps.pl.lab;
+    const uint32_t *g_masks = ps.pl.masks;
+    uint8_t *back = ps.pl.back + ((size_t)chain * len) * BCD_BACK_PITCH;
 
-    tnl = (int *)(bestf + len + 1);
+    tnl = (int *)(bestf + len + 2);
     for (int i = tid; i < 2 * BCD_LDS_LABELS; i += BCD_THREADS) s_dp[i] = 1e300;
     for (int i = tid; i < len; i += BCD_THREADS) {
         int pix = pix0 + i * pstep;
-        bestf[i] = pl.lab[(size_t)pix * LP + ps.bestlabels[pix]].x;
-        tnl[i] = ps.nprop[pix];     // a wave-uniform global load inside the step loop would stall every step (it is
+        bestf[i] = g_lab[(size_t)pix * LP + g_best[pix]].x;
+        tnl[i] = g_nprop[pix];      // a wave-uniform global load inside the step loop would stall every step (it is
                                     // moved to an SGPR at once); the label counts are read from LDS instead
     }
-    if (tid == 0) { bestf[-1] = 0u; bestf[len] = 0u; }       // read, never used (the limit of that side term is 0)
+    if (tid == 0) { bestf[-1] = 0u; bestf[len] = 0u; bestf[len + 1] = 0u; }       // read, never used (the limit of that side term is 0)
     __syncthreads();
 
     // Per-step inputs of this thread: its label's first block and label data, prefetched four steps ahead into four
     // static register slots, and its second / third block (if it owns one: the first block's count says so), fetched two
     // steps ahead.  Rows are LP wide and every first block is initialised, so the first-block and label loads are
-    // unconditional; nothing in a step waits for a load issued in the same step.
+    // unconditional; nothing in a step waits for a load issued in the same step.  The row pointers are wave-uniform and
+    // advance by a constant stride per step (scalar adds); they stop at the chain's last pixel.
     const uint32_t offl = (uint32_t)tl * 8u;
-    const size_t rowl = (size_t)LP * 8u, rowg = (size_t)(BCD_GROUPS * 64) * 8u;
-    auto pixof = [&](int i) { return (size_t)(pix0 + min(i, len - 1) * pstep); };
-    auto fetchA = [&](int i) { return *reinterpret_cast<const uint2 *>((const char *)pl.blkA + (pixof(i) * 2 + dir) * rowl + offl); };
-    auto fetchL = [&](int i) { return *reinterpret_cast<const uint2 *>((const char *)pl.lab + pixof(i) * rowl + offl); };
-    // second / third block of step i, given that step's first block: lanes that own none keep the empty block
-    auto fetchBC = [&](int i, const uint2 &blkA, uint2 &B, uint2 &C) {
+    const long long rowl = (long long)LP * 8, rowg = (long long)(BCD_GROUPS * 64) * 8;
+    const long long strA = (long long)pstep * 2 * rowl, strL = (long long)pstep * rowl, strG = (long long)pstep * 2 * rowg;
+    gptr_t pA = uniform_ptr((const char *)ps.pl.blkA + ((long long)pix0 * 2 + dir) * rowl);      // row of step `nextA`
+    gptr_t pL = uniform_ptr((const char *)ps.pl.lab + (long long)pix0 * rowl);
+    gptr_t pB = uniform_ptr((const char *)ps.pl.blkB + ((long long)pix0 * 2 + dir) * rowg + (long long)wave * 512);   // row of step `nextG`
+    gptr_t pC = uniform_ptr((const char *)ps.pl.blkC + ((long long)pix0 * 2 + dir) * rowg + (long long)wave * 512);
+    int nextA = 0, nextG = 0;
+    auto advA = [&]() { const bool m = nextA + 1 < len; pA += m ? strA : 0; pL += m ? strL : 0; nextA++; };
+    auto advG = [&]() { const bool m = nextG + 1 < len; pB += m ? strG : 0; pC += m ? strG : 0; nextG++; };
+    auto ld8 = [](gptr_t base, uint32_t off) {
+        const unsigned long long v = *reinterpret_cast<const __attribute__((address_space(1))) unsigned long long *>(base + off);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    };
+    // second / third block of the step the (pB, pC) row pointers stand at, given that step's first block: lanes that own
+    // none keep the empty block
+    auto fetchBC = [&](const uint2 &blkA, uint2 &B, uint2 &C) {
         const uint32_t cnt = blkA.y >> 28;
+        const unsigned long long mb = ballot64(cnt > BCD_BLK) & ownmask;
         const bool hb = owner && cnt > BCD_BLK, hc = owner && cnt > 2 * BCD_BLK;
-        const unsigned long long mb = __ballot(hb);
         B = make_uint2(BLK_EMPTY_X, BLK_EMPTY_Y); C = make_uint2(BLK_EMPTY_X, BLK_EMPTY_Y);
         if (mb) {                                                     // wave-uniform
-            const char *gb = (const char *)pl.blkB + (pixof(i) * 2 + dir) * rowg + (size_t)wave * 512u;
-            if (hb) B = *reinterpret_cast<const uint2 *>(gb + lane_rank(mb) * 8u);
-            const unsigned long long mc = __ballot(hc);
-            if (mc) {
-                const char *gc = (const char *)pl.blkC + (pixof(i) * 2 + dir) * rowg + (size_t)wave * 512u;
-                if (hc) C = *reinterpret_cast<const uint2 *>(gc + lane_rank(mc) * 8u);
-            }
+            if (hb) B = ld8(pB, lane_rank(mb) * 8u);
+            const unsigned long long mc = ballot64(cnt > 2 * BCD_BLK) & ownmask;
+            if (mc) { if (hc) C = ld8(pC, lane_rank(mc) * 8u); }
         }
+        advG();
     };
-    uint2 A0, L0 = fetchL(0);
-    uint2 A1 = fetchA(1), L1 = fetchL(1), A2 = fetchA(2), L2 = fetchL(2), A3 = fetchA(3), L3 = fetchL(3);
+    uint2 A0, L0 = ld8(pL, offl); advA();                      // step 0 has no transition: only its label data
+    uint2 A1 = ld8(pA, offl), L1 = ld8(pL, offl); advA();
+    uint2 A2 = ld8(pA, offl), L2 = ld8(pL, offl); advA();
+    uint2 A3 = ld8(pA, offl), L3 = ld8(pL, offl); advA();
     uint2 B1, C1, B0, C0;
-    fetchBC(1, A1, B1, C1);
-    fetchBC(2, A2, B0, C0);
+    advG();
+    fetchBC(A1, B1, C1);
+    fetchBC(A2, B0, C0);
 
     // ---- chain start: dp[0,tl] = (s1 + s2) + lamda*lcost   (python bcd.py:118-120)
     {
@@ -364,7 +395,7 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
         const uint32_t s2 = (im >= 0 && im < len) ? min(tpsi, flow_l1_biased(Fc, bestf[im])) : 0u;
         unsigned long long key = ~0ull;
         if (owner && tl < tnl[0]) {
-            const double d0 = __dadd_rn((double)(s1 + s2), __dmul_rn(a.lamda, (double)__uint_as_float(L0.y)));
+            const double d0 = __dadd_rn((double)(s1 + s2), __dmul_rn(lamda, (double)__uint_as_float(L0.y)));
             s_dp[tl] = d0;
             key = (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, d0));
         }
@@ -372,27 +403,35 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
         const unsigned long long m = wave_key_min_asm(key, &fl);
         if (lane == 0) { permv[wave] = m; permi[wave] = wave * 64 + fl; }
     }
-    A0 = fetchA(4); L0 = fetchL(4);
+    A0 = ld8(pA, offl); L0 = ld8(pL, offl); advA();
     __syncthreads();
 
     int pn = tnl[0];
-    uint8_t *backp = owner ? pl.back + ((size_t)blockIdx.x * len) * LP + tl : pl.back_trash + (tid - LP);   // + i*LP per step
-    const uint32_t bstride = owner ? (uint32_t)LP : 0u;
+    __attribute__((address_space(1))) uint8_t *backrow = (__attribute__((address_space(1))) uint8_t *)uniform_ptr(back + BCD_BACK_PITCH);   // row of step 1; + BCD_BACK_PITCH per step (scalar)
     // One step of the chain; CUR (compile-time) is the LDS buffer this step writes, CUR^1 holds the previous pixel.
     // (inA, inL) = this step's first block and label data, refilled with those of step i+4; (inB, inC) = this step's
     // second / third blocks, refilled with those of step i+2, whose first block `nxA` arrived two steps ago.  The slots
     // are used round-robin by the 4x unrolled loop below, so prefetched registers are never copied while their loads
     // are still in flight.
-    auto step = [&](auto curc, const int i, uint2 &inA, uint2 &inL, uint2 &inB, uint2 &inC, const uint2 &nxA) __attribute__((always_inline)) {
+    // the per-step scalars (label count, flows of the two side neighbours) never change during the kernel: those of step
+    // i+1 are read from LDS during step i
+    int tn_nx = tnl[1];
+    uint32_t bfp_nx = bestf[1 + dirp], bfm_nx = bestf[1 - dirp];
+    auto step = [&](auto curc, auto edgec, const int i, uint2 &inA, uint2 &inL, uint2 &inB, uint2 &inC, const uint2 &nxA) __attribute__((always_inline)) {
         constexpr int CUR = decltype(curc)::value;
+        constexpr bool EDGE = decltype(edgec)::value != 0;     // the chain's last steps: a side neighbour may lie outside
         const char *prev = reinterpret_cast<const char *>(s_dp + (CUR ^ 1) * BCD_LDS_LABELS);
-        const int tn = tnl[i];
+        const int tn = tn_nx;
+        const uint32_t bfp = bfp_nx, bfm = bfm_nx;
+        tn_nx = tnl[min(i + 1, len - 1)];
+        bfp_nx = bestf[i + 1 + dirp]; bfm_nx = bestf[i + 1 - dirp];     // bestf[-1..len+1] exists (see the allocation)
         const uint32_t ax = inA.x, ay = inA.y, bx = inB.x, by = inB.y, cx = inC.x, cy = inC.y;
         const uint32_t Fc = inL.x;
         const float lc = __uint_as_float(inL.y);
+        const unsigned long long actmask = ballot64(tl < tn) & ownmask;
         const bool act = owner && tl < tn;
-        inA = fetchA(i + 4); inL = fetchL(i + 4);
-        fetchBC(i + 2, nxA, inB, inC);
+        inA = ld8(pA, offl); inL = ld8(pL, offl); advA();
+        fetchBC(nxA, inB, inC);
         // min over compatible previous labels (python bcd.py:163-176 / :198-219) in increasing k (strict '<' keeps the
         // first minimum).  Members come as index bytes in increasing k (0xFF = none, which reads the +inf tail of dp)
         // with their pair costs; candidates are tracked by their dp offset 8 k.
@@ -404,21 +443,25 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
         }
         // permmincost / permminlabel (python bcd.py:152-157) merged from the per-wave partials of the previous step (waves
         // are in label order and every partial index is the first one inside its wave), and the unary term
-        // small = (lamda*lcost + s1) + s2 (python bcd.py:161-162; a side neighbour outside the chain contributes 0)
+        // small = (lamda*lcost + s1) + s2 (python bcd.py:161-162; a side neighbour outside the chain contributes 0: its
+        // limit is the scalar 0)
         Cand perm;
         double small;
         {
             const unsigned long long p0 = permv[(CUR ^ 1) * 4], p1 = permv[(CUR ^ 1) * 4 + 1], p2 = permv[(CUR ^ 1) * 4 + 2];
             const int i0 = permi[(CUR ^ 1) * 4], i1 = permi[(CUR ^ 1) * 4 + 1], i2 = permi[(CUR ^ 1) * 4 + 2];
-            const int ip = i + dirp, im = i - dirp;
-            const uint32_t lim1 = (ip >= 0 && ip < len) ? tpsi : 0u, lim2 = (im >= 0 && im < len) ? tpsi : 0u;
-            const uint32_t s1 = min(lim1, flow_l1_biased(Fc, bestf[ip]));
-            const uint32_t s2 = min(lim2, flow_l1_biased(Fc, bestf[im]));
+            uint32_t lim1 = tpsi, lim2 = tpsi;
+            if (EDGE) {
+                const int ip = i + dirp, im = i - dirp;
+                lim1 = (ip >= 0 && ip < len) ? tpsi : 0u; lim2 = (im >= 0 && im < len) ? tpsi : 0u;
+            }
+            const uint32_t s1 = min(flow_l1_biased(Fc, bfp), lim1);
+            const uint32_t s2 = min(flow_l1_biased(Fc, bfm), lim2);
             unsigned long long pmn = p0; int pix_ = i0;
             if (p1 < pmn) { pmn = p1; pix_ = i1; }
             if (p2 < pmn) { pmn = p2; pix_ = i2; }
             perm.v = __longlong_as_double((long long)pmn); perm.k = pix_;
-            small = __dadd_rn(__dadd_rn(__dmul_rn(a.lamda, (double)lc), (double)s1), (double)s2);
+            small = __dadd_rn(__dadd_rn(__dmul_rn(lamda, (double)lc), (double)s1), (double)s2);
         }
         double bestv = 1e300; uint32_t besta = 0x7fffffffu;
 #pragma unroll
@@ -428,7 +471,7 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
             bestv = __builtin_fmin(bestv, c); besta = t ? ad[j] : besta;
         }
         // second block: some label of the wave has more than 5 members (almost always true for a full wave)
-        if (__ballot(act && (ay >> 28) > BCD_BLK) != 0ull) {
+        if ((ballot64((ay >> 28) > BCD_BLK) & actmask) != 0ull) {
             uint32_t a2[BCD_BLK]; double d2[BCD_BLK];
 #pragma unroll
             for (int j = 0; j < BCD_BLK; j++) { a2[j] = ((j < 4 ? bx >> (8 * j) : by) & 0xFFu) << 3; d2[j] = *reinterpret_cast<const double *>(prev + a2[j]); }
@@ -439,7 +482,7 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
                 bestv = __builtin_fmin(bestv, c); besta = t ? a2[j] : besta;
             }
             // third block (a quarter of the waves), rows beyond 15 members (2 % of the workgroup steps)
-            if (__builtin_expect(__ballot(act && (ay >> 28) > 2 * BCD_BLK) != 0ull, 0)) {
+            if (__builtin_expect((ballot64((ay >> 28) > 2 * BCD_BLK) & actmask) != 0ull, 0)) {
 #pragma unroll
                 for (int j = 0; j < BCD_BLK; j++) { a2[j] = ((j < 4 ? cx >> (8 * j) : cy) & 0xFFu) << 3; d2[j] = *reinterpret_cast<const double *>(prev + a2[j]); }
 #pragma unroll
@@ -449,14 +492,14 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
                     bestv = __builtin_fmin(bestv, c); besta = t ? a2[j] : besta;
                 }
                 const bool more = act && (ay & 0x800u) != 0u;
-                if (__builtin_expect(__ballot(more) != 0ull, 0)) {
+                if (__builtin_expect(ballot64(more) != 0ull, 0)) {
                     // denser rows still: those lanes fetch their 160-bit row and walk what is left behind the 15th list
                     // member, four set bits per round; still increasing k, so strict '<' stands.  The predecessor's
                     // flows come from its label data (this path is rare; everything it reads is L2-resident)
                     const int k14 = (int)(cy & 0xFFu);
                     const size_t cpix = (size_t)(pix0 + i * pstep), ppix = (size_t)(pix0 + (i - 1) * pstep);
-                    const uint32_t *mrow = pl.masks + ((cpix * 2 + dir) * LP + tl) * BCD_MASK_WORDS;
-                    const uint2 *plab = pl.lab + ppix * LP;
+                    const uint32_t *mrow = g_masks + ((cpix * 2 + dir) * LP + tl) * BCD_MASK_WORDS;
+                    const uint2 *plab = g_lab + ppix * LP;
                     unsigned long long w0 = 0, w1 = 0, w2 = 0;
                     if (more) {
                         w0 = (unsigned long long)mrow[0] | ((unsigned long long)mrow[1] << 32);
@@ -491,8 +534,8 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
             }
         }
         // No branch on `act`: the slots of labels beyond this pixel's count (dp, back-pointer) may hold anything, no
-        // list and no traceback refers to them; the shadow lanes (tid >= 160) write to LDS slots 160..191 (equally
-        // unreferenced) and to a trash line behind the back-pointer array.
+        // list and no traceback refers to them; the shadow lanes (tid >= LP) write to LDS slots LP..191 and to
+        // back-pointer columns LP..191, equally unreferenced.
         unsigned long long key;
         {
             const bool found = besta != 0x7fffffffu;
@@ -500,7 +543,8 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
             const int pl_ = found ? (int)(besta >> 3) : perm.k;
             const double dpc = __dadd_rn(mincost, small);
             s_dp[CUR * BCD_LDS_LABELS + tid] = dpc;
-            backp[(size_t)i * bstride] = (uint8_t)pl_;
+            backrow[tid] = (uint8_t)pl_;
+            backrow += BCD_BACK_PITCH;
             key = act ? (unsigned long long)__double_as_longlong(__dadd_rn(tpsi_d, dpc)) : ~0ull;
         }
         {
@@ -517,15 +561,16 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
     };
     // step i: first block / label slot i mod 4, second / third block slot i mod 2, next-next first block = slot (i+2) mod 4
     int i = 1;
-    for (; i + 3 < len; i += 4) {                       // whole groups of four without per-step bounds checks
-        step(IntC<1>(), i, A1, L1, B1, C1, A3);
-        step(IntC<0>(), i + 1, A2, L2, B0, C0, A0);
-        step(IntC<1>(), i + 2, A3, L3, B1, C1, A1);
-        step(IntC<0>(), i + 3, A0, L0, B0, C0, A2);
+    for (; i + 4 < len; i += 4) {                       // whole groups of four interior steps (both side neighbours on the chain)
+        step(IntC<1>(), IntC<0>(), i, A1, L1, B1, C1, A3);
+        step(IntC<0>(), IntC<0>(), i + 1, A2, L2, B0, C0, A0);
+        step(IntC<1>(), IntC<0>(), i + 2, A3, L3, B1, C1, A1);
+        step(IntC<0>(), IntC<0>(), i + 3, A0, L0, B0, C0, A2);
     }
-    if (i < len) step(IntC<1>(), i, A1, L1, B1, C1, A3);
-    if (i + 1 < len) step(IntC<0>(), i + 1, A2, L2, B0, C0, A0);
-    if (i + 2 < len) step(IntC<1>(), i + 2, A3, L3, B1, C1, A1);
+    if (i < len) step(IntC<1>(), IntC<1>(), i, A1, L1, B1, C1, A3);
+    if (i + 1 < len) step(IntC<0>(), IntC<1>(), i + 1, A2, L2, B0, C0, A0);
+    if (i + 2 < len) step(IntC<1>(), IntC<1>(), i + 2, A3, L3, B1, C1, A1);
+    if (i + 3 < len) step(IntC<0>(), IntC<1>(), i + 3, A0, L0, B0, C0, A2);
     const int cur = (len & 1) ? 1 : 0;         // the buffer the step after the last one would write; the last written is cur^1
 
     // ---- end label: first minimum of dp[len-1] (python bcd.py:231-237): tpsi + dp is monotone in dp, but two different
@@ -539,19 +584,18 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
     }
     __syncthreads();
     // ---- traceback (python bcd.py:239-253): chunks of back-pointer rows are staged in LDS, one thread walks them
-    uint8_t *back = pl.back + ((size_t)blockIdx.x * len) * LP;
     int plb = *s_label;
-    if (tid == 0) ps.bestlabels[pix0 + (len - 1) * pstep] = plb;
+    if (tid == 0) g_best[pix0 + (len - 1) * pstep] = plb;
     for (int hi = len - 1; hi >= 1; hi -= BCD_TB_STEPS) {
         const int lo = max(1, hi - BCD_TB_STEPS + 1);      // steps lo..hi
-        const int nbytes = (hi - lo + 1) * LP;
-        const uint4 *src = reinterpret_cast<const uint4 *>(back + (size_t)lo * LP);
+        const int nbytes = (hi - lo + 1) * BCD_BACK_PITCH;
+        const uint4 *src = reinterpret_cast<const uint4 *>(back + (size_t)lo * BCD_BACK_PITCH);
         for (int j = tid; j < nbytes / 16; j += BCD_THREADS) reinterpret_cast<uint4 *>(tb)[j] = src[j];
         __syncthreads();
         if (tid == 0) {
             for (int i2 = hi; i2 >= lo; i2--) {
-                plb = tb[(i2 - lo) * LP + plb];
-                ps.bestlabels[pix0 + (i2 - 1) * pstep] = plb;
+                plb = tb[(i2 - lo) * BCD_BACK_PITCH + plb];
+                g_best[pix0 + (i2 - 1) * pstep] = plb;
             }
             *s_label = plb;
         }
@@ -577,10 +621,10 @@ static size_t back_bytes(const dflow_params *p)
     for (int ph = 0; ph < 4; ph++) {
         int n, len;
         phase_dims(p, ph, n, len);
-        size_t b = (size_t)n * len * p->label_pitch;
+        size_t b = (size_t)n * len * BCD_BACK_PITCH;
         if (b > m) m = b;
     }
-    return align256(m) + 256;      // + a trash line for the shadow lanes of the chain kernel
+    return align256(m) + 256;
 }
 
 static size_t lab_bytes(const dflow_params *p) { return align256((size_t)p->pich * p->picw * p->label_pitch * 8); }
@@ -597,7 +641,7 @@ static BcdPlanes planes_of(const dflow_params *p, void *ws)
 {
     BcdPlanes pl;
     char *w = (char *)ws;
-    pl.back = (uint8_t *)w; pl.back_trash = (uint8_t *)w + back_bytes(p) - 256; w += back_bytes(p);
+    pl.back = (uint8_t *)w; w += back_bytes(p);
     pl.lab = (uint2 *)w; w += lab_bytes(p);
     pl.blkA = (uint2 *)w; w += blka_bytes(p);
     pl.blkB = (uint2 *)w; w += blkg_bytes(p);
@@ -621,7 +665,7 @@ int launch_bcd_phase_batch(const dflow_params *p, int npass, const int32_t *cons
     int nchains, len;
     phase_dims(p, phase, nchains, len);
     if (nchains == 0) return DFLOW_OK;
-    size_t shmem = (size_t)(len + 2) * sizeof(uint32_t) + (size_t)len * sizeof(int);
+    size_t shmem = (size_t)(len + 4) * sizeof(uint32_t) + (size_t)len * sizeof(int);
     for (int b0 = 0; b0 < npass; b0 += BCD_MAX_BATCH) {
         const int nb = npass - b0 < BCD_MAX_BATCH ? npass - b0 : BCD_MAX_BATCH;
         BcdArgs a;
