@@ -182,6 +182,8 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, const float *__rest
         r = hp;
 #pragma unroll
         for (int i = 0; i < 3; i++) { _Float16 pc = (_Float16)r; row[71 + i] = pc; r = r - (float)pc; }
+        // multipliers of the query's threshold pieces (pass 2 of the screen subtracts the threshold inside the MFMA)
+        row[74] = (_Float16)1.0f; row[75] = (_Float16)1.0f; row[76] = (_Float16)1.0f;
     }
     float4 *o = reinterpret_cast<float4 *>(h + orow * KM_K);
     const float4 *r4 = reinterpret_cast<const float4 *>(row);
@@ -220,24 +222,35 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     const Geom g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
-    // ---- which (candidate cell, query cell in its window, query chunk).  Candidate-cell-major order: the blocks in
-    // flight at any time stream the same few candidate cells, so their rows stay in the XCDs' L2.
+    // ---- which candidate cell, and which 64-query wave of which query cell in its window.  A workgroup streams ONE
+    // candidate cell; its 8 waves take 8 consecutive entries of the flat list of (window slot, 64-query wave) pairs of
+    // that cell, so waves of one workgroup may belong to different query cells and no wave idles except in the last
+    // workgroup of a cell (a cell has 27 waves of queries at 64x27: chunks of 8 per query cell would leave 5 of 32 idle).
+    // Candidate-cell-major order: the blocks in flight at any time stream the same few candidate cells, so their rows
+    // stay in the XCDs' L2.
     const int win = 2 * g.win + 1;
-    const int qchunks = (a.qwaves + KM_WAVES - 1) / KM_WAVES;
-    int b = blockIdx.x;
-    const int qchunk = b % qchunks; b /= qchunks;
-    const int qslot = b % (win * win); const int ccell = b / (win * win);
+    const int wgs_per_cell = (win * win * a.qwaves + KM_WAVES - 1) / KM_WAVES;
+    const int ccell = blockIdx.x / wgs_per_cell, w8 = blockIdx.x % wgs_per_cell;
     const int ci = ccell % g.ncx, cj = ccell / g.ncx;
-    const int qci = ci - g.win + qslot / win, qcj = cj - g.win + qslot % win;
-    if (qci < 0 || qci >= g.ncx || qcj < 0 || qcj >= g.ncy) return;
+    int flat = w8 * KM_WAVES + __builtin_amdgcn_readfirstlane(wave);
+    int total = 0, qci = -1, qcj = -1, qwave = 0, fqci = -1, fqcj = -1;
+    for (int qslot = 0; qslot < win * win; qslot++) {          // wave-uniform scan of the window (<= 25 slots)
+        const int sci = ci - g.win + qslot / win, scj = cj - g.win + qslot % win;
+        if (sci < 0 || sci >= g.ncx || scj < 0 || scj >= g.ncy) continue;
+        const int nw = ((g.x1(sci) - g.x0(sci)) * (g.y1(scj) - g.y0(scj)) + KM_QPW - 1) / KM_QPW;
+        if (fqci < 0) { fqci = sci; fqcj = scj; }
+        if (qci < 0 && flat >= total && flat < total + nw) { qci = sci; qcj = scj; qwave = flat - total; }
+        total += nw;
+    }
+    if (w8 * KM_WAVES >= total) return;                               // block-uniform: nothing left for this workgroup
+    const bool wave_active = qci >= 0;                                // idle waves only help staging (barriers stay block-uniform)
+    if (!wave_active) { qci = fqci; qcj = fqcj; qwave = 0; }         // they shadow a valid query wave and store nothing
     const int qcell = qcj * g.ncx + qci;
     const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
-    if (qchunk * KM_QPB >= qnpts) return;
     const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
     const int wslot = (ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin);   // reference order: ci outer, cj inner (Q2)
     const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0, cnpts = ccw * (g.y1(cj) - cy0);
-    const int qwave = qchunk * KM_WAVES + wave;
-    const bool wave_active = qwave * KM_QPW < qnpts;                   // idle waves only help staging (barriers stay block-uniform)
+    (void)cx0; (void)cy0;
 
     // ---- my queries: group gq (0/1), column col; B fragments (last k-step differs between the passes) and slack
     half8 bfrag[2][5], blast2[2];
@@ -282,7 +295,6 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     };
 
     float a5[2][5];
-    float thr[2] = {0.f, 0.f};
     int cnt[2] = {0, 0};
     const size_t lid = list_id(a, qcell, qwave, wslot);
     uint32_t *myev = p.ev + lid * KM_LIST_WORDS + lane;
@@ -310,20 +322,19 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     // Pass 2: 16-bit mask of the rows that qualify (bit r <-> accumulator register r) -> one event word.
     auto epi1 = [&](const f32x16 &acc, int gq) { top5_insert_desc(a5[gq], max16(acc)); };
     auto epi2 = [&](const f32x16 &acc, int gq, int tileidx) {
-        const float th = thr[gq];
-        // The compiler pads MFMA -> VALU hazards only for instructions it emits itself, so a plain max over the
-        // accumulator comes first and the asm below is made to depend on it.
-        uint32_t mask = max16(acc) >= th ? 0u : 0x10000u;   // bit 16 set <=> no row qualifies
+        // pass 2 accumulates v - th' (the threshold rides in the k = 74..76 products), so a row qualifies iff its
+        // accumulator is not negative: one v_alignbit per row shifts the sign bit into the mask (bit r <-> register r)
+        uint32_t neg = 0u;
 #pragma unroll
-        for (int r = 15; r >= 0; r--)   // mask = 2 mask + (acc[r] >= th): compare into vcc, add with carry-in
-            asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(acc[r]), "v"(th) : "vcc");
-        mask &= 0xFFFFu;
+        for (int r = 15; r >= 0; r--) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(acc[r]), 31);
+        const uint32_t mask = ~neg & 0xFFFFu;
         // always one store: real entries go to row cnt, empty masks to the scratch row KM_EVROWS-1 (a list that needs
         // that row for data is reported as overflowed)
         const int row = mask ? min(cnt[gq], KM_EVROWS - 1) : KM_EVROWS - 1;
         myev[(size_t)(gq * KM_EVROWS + row) * 64] = ((uint32_t)tileidx << 16) | mask;
         cnt[gq] += mask ? 1 : 0;
     };
+    // the pipeline starts with a harmless unit: -inf never enters a top-5 (pass 1) and is negative (pass 2)
     const f32x16 minus_inf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY,
                               -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int pass = 0; pass < 2; pass++) {
@@ -377,8 +388,19 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
                 for (int i = 0; i < 5; i++) top5_insert_desc(a5[gq], o[i]);
                 const float a5v = a5[gq][4];
                 const float x = a5v - 2.0f * sq[gq] - 2.2e-5f * (hq[gq] - a5v + sq[gq]);
-                thr[gq] = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -55000.0f);   // real values are > -50000, sentinel rows -60000
-                bfrag[gq][4] = blast2[gq];                                      // pass 2 selects h+
+                const float th = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -55000.0f);   // real values are > -50000, sentinel rows -60000
+                // Pass 2 subtracts the threshold inside the matrix core: three f16 pieces of th' (33 bits) times the 1.0 the
+                // candidate rows carry at k = 74..76.  th' lies below th by the accumulation allowance eta on the three extra
+                // products (|pieces| <= |th'|) and by more than the pieces' truncation (< 2^-24 absolute each), so
+                // v >= th implies a computed v - th' >= 0; sentinel rows (-60000, no 1.0) stay negative.
+                const float thp = th - 2.6e-4f * fabsf(th) - 1e-5f;
+                half8 b2 = blast2[gq];                                          // pass 2 selects h+
+                if (half == 1) {
+                    float r = thp;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { const _Float16 pc = (_Float16)r; b2[2 + i] = -pc; r = r - (float)pc; }
+                }
+                bfrag[gq][4] = b2;
             }
         }
     }
@@ -651,11 +673,11 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     a.g = g; a.LP = p->label_pitch; a.tphi = p->tphi;
     a.qwaves = (max_cell_points(g) + KM_QPW - 1) / KM_QPW;
     int win = 2 * g.win + 1;
-    int qchunks = (a.qwaves + KM_WAVES - 1) / KM_WAVES;
+    int wgs_per_cell = (win * win * a.qwaves + KM_WAVES - 1) / KM_WAVES;
     KmScreen sc;
     sc.h1 = h1; sc.h2 = h2; sc.qs = qs; sc.ev = ev; sc.ev_cnt = ev_cnt;
     size_t shmem = (size_t)KM_NBUF * KM_ABUF;
-    hipLaunchKernelGGL(knn_screen_kernel, dim3(g.ncx * g.ncy * qchunks * win * win), dim3(KM_THREADS), shmem, s, a, sc);
+    hipLaunchKernelGGL(knn_screen_kernel, dim3(g.ncx * g.ncy * wgs_per_cell), dim3(KM_THREADS), shmem, s, a, sc);
     int rc = dflow_check_launch("knn_screen_kernel");
     if (rc) return rc;
     KmResolve rs;
