@@ -280,11 +280,106 @@ class GpuEngine:
             df.ceoBCD(BCD_TIMES)
             if timed:
                 e1.record()
-                self.bcd_events.append((e0, e1))
+                self.bcd_events.append((e0, e1, 1))
             flow = df.vratiKonacniFlow()
             if self.gather is not None:
                 self.gather(flow, i % self.P)
         return flow
+
+    def begin(self, nsteps):
+        pass
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+class BatchEngine:
+    """Steps are processed in groups of `batch` pairs: the front end of every pair of a group (DAISY, kNN proposals,
+    neighbour proposals, compat lists) runs on one of `front` HIP streams, then the BCD sweeps of the whole group run as
+    ONE batched launch per phase (dflow_bcd_sweep_batch: chains x passes in one grid), then labels -> flow and the gather.
+    Two sets of per-pair state alternate, so the front end of group g+1 overlaps the sweeps of group g.  Every step is
+    still one complete pass over one pair; the timed region contains exactly `steps` of them (the last group may be
+    smaller)."""
+
+    def __init__(self, args, rank, local_rank, world):
+        import torch
+        self.torch = torch
+        self.synth = importlib.import_module(PKG + ".synth")
+        self.pipeline = importlib.import_module(PKG + ".pipeline")
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.backend = "nccl"
+        self.rank = rank
+        self.cellh, self.cellw = self.pipeline.default_cells(H, W)
+        self.B = max(1, args.batch)
+        self.P = self.B
+        self.sets = [[self.pipeline.DiscreteFlow(H, W, self.cellh, self.cellw, device=self.dev, seed=rank) for _ in range(self.B)]
+                     for _ in range(2)]
+        self.flows = self.sets[0]
+        self.front = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, args.front))]
+        self.bcd_stream = torch.cuda.Stream(device=self.dev)
+        self.set_free = [None, None]            # event: the set's previous sweeps + flow read-out are done
+        self.seeds = [self.synth.pair_seed(2 * rank + j, 0) for j in range(2)]
+        self.pairs = []
+        for sd in self.seeds:
+            img1, img2, _ = self.synth.make_pair(H, W, seed=sd)
+            self.pairs.append((torch.from_numpy(img1).to(self.dev), torch.from_numpy(img2).to(self.dev)))
+        self.bcd_events = []
+        self.gather = None
+        self.pending = []                       # step indices of the group being collected
+        self.group_no = 0
+        self.nsteps = None
+
+    def like(self):
+        return self.flows[0].flow
+
+    def begin(self, nsteps):
+        self.pending, self.nsteps, self.done = [], nsteps, 0
+
+    def step(self, i, timed):
+        self.pending.append(i)
+        self.done += 1
+        if len(self.pending) == self.B or self.done == self.nsteps:
+            self._run_group(self.pending, timed)
+            self.pending = []
+
+    def _run_group(self, idx, timed):
+        torch = self.torch
+        k = self.group_no % 2
+        self.group_no += 1
+        dfs = self.sets[k][:len(idx)]
+        evs = []
+        for j, i in enumerate(idx):
+            st = self.front[j % len(self.front)]
+            a, b = self.pairs[i % 2]
+            with torch.cuda.stream(st):
+                if self.set_free[k] is not None:
+                    st.wait_event(self.set_free[k])
+                df = dfs[j]
+                df.load_pair(a, b)
+                df.generisi()
+                df.nasumicni()
+                df.pakovanje()
+                e = torch.cuda.Event()
+                e.record()
+                evs.append(e)
+        with torch.cuda.stream(self.bcd_stream):
+            for e in evs:
+                self.bcd_stream.wait_event(e)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.pipeline.ceoBCD_batch(dfs, BCD_TIMES)
+            if timed:
+                e1.record()
+                self.bcd_events.append((e0, e1, len(idx)))
+            for j, df in enumerate(dfs):
+                flow = df.vratiKonacniFlow()
+                if self.gather is not None:
+                    self.gather(flow, j)
+            done = torch.cuda.Event()
+            done.record()
+            self.set_free[k] = done
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -312,6 +407,9 @@ class StubEngine:
             self.gather(self.field, 0)
         return self.field
 
+    def begin(self, nsteps):
+        pass
+
     def sync(self):
         pass
 
@@ -328,7 +426,7 @@ def worker(args):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.stub and os.environ.get("DFLOW_BENCH_FAIL_RANK") == str(rank):
         raise SystemExit(3)                       # tests/test_bench_launcher.py: a failing rank must fail the launcher
-    eng = (StubEngine if args.stub else GpuEngine)(args, rank, local_rank, world)
+    eng = (StubEngine if args.stub else (BatchEngine if args.mode == "batch" else GpuEngine))(args, rank, local_rank, world)
     # under a launcher (ours or torch.distributed.run) the process group is always created, also for one rank, which
     # exercises the same RCCL gather path; a plain `python bench.py` runs without torch.distributed
     use_dist = "RANK" in os.environ
@@ -340,6 +438,7 @@ def worker(args):
         bufs = [sharding.make_gather_buffers(eng.like(), world, rank) for _ in range(eng.P)]
         eng.gather = lambda flow, slot: sharding.gather_flows(flow, bufs[slot], rank)
 
+    eng.begin(args.warmup)
     for i in range(args.warmup):
         eng.step(i, False)
 
@@ -351,6 +450,7 @@ def worker(args):
 
     sync_all()
     t0 = time.perf_counter()
+    eng.begin(args.steps)
     for i in range(args.steps):
         eng.step(i, True)
     sync_all()
@@ -383,23 +483,31 @@ def finish_report(out, eng, args, world):
     P = eng.P
     out["config"] = {"workload": "single 1024x436 Sintel-shape pair per step per GPU, forward only, bcd_times=4 "
                                  "(BASELINE.json configs[1]); cells 64x27, 150 labels/px",
-                     "pairs_in_flight_per_gpu": P, "pair_seeds_rank0": eng.seeds,
-                     "parallelism": "one pass per step; %d independent steps in flight per GPU on separate HIP streams; "
-                                    "flow fields gathered on rank 0" % P}
+                     "pairs_in_flight_per_gpu": P, "pair_seeds_rank0": eng.seeds, "mode": args.mode,
+                     "parallelism": ("one pass per step, steps in groups of %d: front end of a group's pairs on %d HIP streams, the "
+                                     "BCD sweeps of the group as one batched launch per phase (chains x passes), two groups "
+                                     "alternate so that front end and sweeps of consecutive groups overlap; flow fields gathered "
+                                     "on rank 0" % (P, args.front)) if args.mode == "batch" else
+                                    ("one pass per step; %d independent steps in flight per GPU on separate HIP streams; "
+                                     "flow fields gathered on rank 0" % P)}
     # dominant kernel of a step: bcd_chain_kernel, 4 sweeps x 4 phases = 16 launches between the two events
     launches = 4 * BCD_TIMES
-    bcd_ms = sum(a.elapsed_time(b) for a, b in eng.bcd_events) / max(1, len(eng.bcd_events)) / launches
+    # (start, end, passes in the launch): a batched launch carries the chains of several passes
+    bcd_ms = sum(a.elapsed_time(b) for a, b, _ in eng.bcd_events) / max(1, len(eng.bcd_events)) / launches
+    passes_per_launch = sum(n for _, _, n in eng.bcd_events) / max(1, len(eng.bcd_events))
     # algorithmic bytes of one phase launch: every pixel of half the image lines is visited once and
     # needs its labels: L*4 B flows + L*4 B costs + 16 B per pixel, L = 150  ->  1216 B per visited pixel
-    alg_bytes = (H * W // 2) * (150 * 4 + 150 * 4 + 16)
+    alg_bytes = int(passes_per_launch * (H * W // 2) * (150 * 4 + 150 * 4 + 16))
     achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic("bcd_chain_kernel")
     out["roofline"] = {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "traffic": traffic, "traffic_source": traffic_src,
-                       "launch_ms": bcd_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                       "note": "launch_ms = HIP-event time of the 16 chain launches of a step / 16, measured on the launch "
-                               "stream with %d pairs in flight" % P}
+                       "launch_ms": bcd_ms, "passes_per_launch": passes_per_launch, "algorithmic_bytes_per_launch": alg_bytes,
+                       "launch_ms_per_pass": bcd_ms / passes_per_launch,
+                       "note": "launch_ms = HIP-event time of the 16 chain launches of a group of passes / 16, measured on the "
+                                       "launch stream (%s mode, %d pairs per group / in flight); traffic = rocprofv3 PMC bytes of one "
+                                       "such launch (profiles/)" % (args.mode, P)}
     out["roofline"]["stages"] = stage_rooflines(torch, eng.flows[0], eng.pairs[0], eng.cellh, eng.cellw)
     # flow of the bench's first pair (what the EPE numbers refer to)
     df = eng.flows[0]
@@ -420,6 +528,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent pairs in flight per GPU (each on its own HIP stream and workspace)")
+    ap.add_argument("--mode", choices=("streams", "batch"), default="batch",
+                    help="streams: --inflight independent pipelines; batch: groups of --batch pairs share the BCD launches")
+    ap.add_argument("--batch", type=int, default=6, help="pairs per group in --mode batch")
+    ap.add_argument("--front", type=int, default=3, help="HIP streams for the front end of a group in --mode batch")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:

@@ -52,7 +52,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KM_EVLIST 64             // candidates per lane and group the resolve kernel lists in LDS
 #define KM_T 1.7263349e-4f                       // t = 2^-12.5: split of the cross terms |q~||E_c|, |E_q||c| (see header)
 #define KM_ETA 2.44140625e-4f                    // eta = 2^-12: allowance for the f32 accumulation inside the matrix core
-#define KM_MEAN_SAMPLES 4096
+#define KM_MEAN_SAMPLES 1024
 
 struct KmGeom {
     Geom g;
@@ -85,7 +85,7 @@ __host__ __device__ static inline size_t km_total_rows(const Geom &g)
     return km_cell_base(g, 0, g.ncy - 1) + (size_t)(g.ncx - 1) * km_pad(g.cw * hl) + km_pad(wl * hl);
 }
 
-// mu = mean descriptor over KM_MEAN_SAMPLES evenly spaced pixels of image 2: one block, thread = (dimension, sample group),
+// mu = mean descriptor over KM_MEAN_SAMPLES (1024: the single block is latency-bound) evenly spaced pixels of image 2: one block, thread = (dimension, sample group),
 // partial sums combined in a fixed order.  Any mu gives exact results; a good one makes the screen tight.
 __global__ void __launch_bounds__(1024) knn_mean_kernel(const float *__restrict__ d, float *__restrict__ mu, int npix)
 {
