@@ -221,14 +221,18 @@ def stage_rooflines(torch, df, pair, cellh, cellw, reps=3):
     }
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, grids=None):
     """HBM bytes per launch of `kernel` from the tracked rocprofv3 --pmc summary (profiles/pmc_traffic.json, written by
-    scratch/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE passes of this command; FETCH_SIZE already doubled as
-    MI355X_MICROARCH.md prescribes for gfx950's wide reads).  None if the file has no entry."""
+    scratch/pmc_to_json.py from separate FETCH_SIZE and WRITE_SIZE passes of this command; FETCH_SIZE already doubled as
+    MI355X_MICROARCH.md prescribes for gfx950's wide reads).  `grids` = launch sizes in threads to average over (the
+    profiled command also launches the kernel in other geometries); None if the file has no matching entry."""
     try:
         with open(PMC_TRAFFIC_FILE) as f:
             d = json.load(f)
         e = d["kernels"][kernel]
+        if grids:
+            v = [e["by_grid_threads"][str(g)]["hbm_bytes_per_launch"] for g in grids]
+            return int(sum(v) / len(v)), d.get("source", PMC_TRAFFIC_FILE)
         return int(e["hbm_bytes_per_launch"]), d.get("source", PMC_TRAFFIC_FILE)
     except Exception:
         return None, None
@@ -499,7 +503,10 @@ def finish_report(out, eng, args, world):
     # needs its labels: L*4 B flows + L*4 B costs + 16 B per pixel, L = 150  ->  1216 B per visited pixel
     alg_bytes = int(passes_per_launch * (H * W // 2) * (150 * 4 + 150 * 4 + 16))
     achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic("bcd_chain_kernel")
+    # the launches of the timed region: column phases (W+1)//2 resp. W//2 chains, row phases (H+1)//2 resp. H//2 chains,
+    # 192 threads per chain, times the passes of a group
+    ppl = int(round(passes_per_launch))
+    traffic, traffic_src = pmc_traffic("bcd_chain_kernel", [((W + 1) // 2) * 192 * ppl, ((H + 1) // 2) * 192 * ppl])
     out["roofline"] = {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "traffic": traffic, "traffic_source": traffic_src,
