@@ -35,6 +35,7 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int V> struct KmC { static constexpr int value = V; };
 
 #define KM_ALPHA 64.0f
 #define KM_K 80                 // f16 per prepared row (160 bytes)
@@ -337,6 +338,48 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     // the pipeline starts with a harmless unit: -inf never enters a top-5 (pass 1) and is negative (pass 2)
     const f32x16 minus_inf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY,
                               -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    // the tiles of one staged chunk; PASS is a compile-time constant (the scheduling directives need constants)
+    f32x16 pend;
+    int pend_tile = 0;
+    auto tiles = [&](auto passc, const int chunk, const char *ab) __attribute__((always_inline)) {
+        constexpr int PASS = decltype(passc)::value;
+#pragma unroll 1
+        for (int tile = 0; tile < KM_CHUNK / 32; tile++) {
+            const int tileidx = chunk * (KM_CHUNK / 32) + tile;
+            half8 af[5];
+            const char *arow = ab + (tile * 32 + col) * KM_PITCH + half * 16;
+#pragma unroll
+            for (int s = 0; s < 5; s++) af[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            // unit (tile, group 0): its five MFMAs (one dependent chain, 32 cycles each) with the pending epilogue of
+            // (previous tile, group 1) issued in their shadow, a few VALU per MFMA: the scheduler is told to build that
+            // pipeline (sched_group_barrier) and not to mix the two halves (sched_barrier), otherwise it clusters the
+            // MFMAs of both groups and the epilogues behind them, and the waves of a SIMD then alternate in lockstep
+            // between matrix-only and vector-only phases (matrix pipe 55 % busy)
+            f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 5; s++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[0][s], acc0, 0, 0, 0);
+            if (PASS == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile);
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 3 : 5, 0);   // VALU of the epilogue in its shadow
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // unit (tile, group 1): MFMAs, in their shadow the epilogue of (tile, group 0)
+            f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 5; s++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[1][s], acc1, 0, 0, 0);
+            if (PASS == 0) epi1(acc0, 0); else epi2(acc0, 0, tileidx);
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 3 : 5, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pend = acc1; pend_tile = tileidx;
+        }
+    };
     for (int pass = 0; pass < 2; pass++) {
         stage(0, 0); stage(1, 1); stage(2, 2);
         if (n_w == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -344,33 +387,13 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         __builtin_amdgcn_s_barrier();
         // Software pipeline: the epilogue of the previous (tile, group) unit is issued behind the MFMAs of the current
         // one, so the VALU work runs while the matrix pipe is busy.  The pipeline starts with a harmless unit (-inf).
-        f32x16 pend = minus_inf;
-        int pend_tile = 0;
+        pend = minus_inf;
+        pend_tile = 0;
         for (int chunk = 0; chunk < nchunks; chunk++) {
             const int buf = chunk & (KM_NBUF - 1);
             stage(chunk + 3, (chunk + 3) & (KM_NBUF - 1));                // that buffer was released by the previous barrier
             const char *ab = abuf + (size_t)buf * KM_ABUF;
-            if (wave_active) {
-#pragma unroll 1
-                for (int tile = 0; tile < KM_CHUNK / 32; tile++) {
-                    const int tileidx = chunk * (KM_CHUNK / 32) + tile;
-                    half8 af[5];
-                    const char *arow = ab + (tile * 32 + col) * KM_PITCH + half * 16;
-#pragma unroll
-                    for (int s = 0; s < 5; s++) af[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
-                    // unit (tile, group 0): MFMAs, then the pending epilogue of (previous tile, group 1)
-                    f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 5; s++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[0][s], acc0, 0, 0, 0);
-                    if (pass == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile);
-                    // unit (tile, group 1): MFMAs, then the epilogue of (tile, group 0)
-                    f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 5; s++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[1][s], acc1, 0, 0, 0);
-                    if (pass == 0) epi1(acc0, 0); else epi2(acc0, 0, tileidx);
-                    pend = acc1; pend_tile = tileidx;
-                }
-            }
+            if (wave_active) { if (pass == 0) tiles(KmC<0>(), chunk, ab); else tiles(KmC<1>(), chunk, ab); }
             wait_ring(pass);
         }
         if (wave_active) { if (pass == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile); }   // drain the pipeline
