@@ -537,7 +537,7 @@ def main():
                     help="independent pairs in flight per GPU (each on its own HIP stream and workspace)")
     ap.add_argument("--mode", choices=("streams", "batch"), default="batch",
                     help="streams: --inflight independent pipelines; batch: groups of --batch pairs share the BCD launches")
-    ap.add_argument("--batch", type=int, default=6, help="pairs per group in --mode batch")
+    ap.add_argument("--batch", type=int, default=8, help="pairs per group in --mode batch")
     ap.add_argument("--front", type=int, default=3, help="HIP streams for the front end of a group in --mode batch")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
