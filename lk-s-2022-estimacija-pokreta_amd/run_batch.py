@@ -27,6 +27,7 @@ def main(argv=None):
     ap.add_argument("--size", default="436x1024")
     ap.add_argument("--thresh", type=float, default=10.0)     # README.md:65 of the reference
     ap.add_argument("--out", default=".")
+    ap.add_argument("--group", type=int, default=4, help="passes of a rank whose BCD sweeps share their launches")
     a = ap.parse_args(argv)
     import torch
     import torch.distributed as dist
@@ -42,24 +43,34 @@ def main(argv=None):
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    df = pipeline.DiscreteFlow(H, W, device=dev, seed=rank)
     passes = [(pair, backward) for pair in range(a.pairs) for backward in (0, 1)]
-
-    # this rank's pairs are generated and uploaded BEFORE the passes run: compute() is GPU work only
+    # this rank's pairs are generated and uploaded BEFORE the passes run: the compute functions are GPU work only
     mine = sharding.assign_passes(len(passes), world, rank)
     images = {}
     for pair in sorted({passes[i][0] for i in mine}):
         img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(pair, 0))
         images[pair] = (torch.from_numpy(img1).to(dev), torch.from_numpy(img2).to(dev))
+    # the passes of a rank (forward and backward runs, several pairs) are independent: their front ends run one after the
+    # other, their BCD sweeps as batched launches (dflow_bcd_sweep_batch), `group` passes at a time
+    group = max(1, min(a.group, len(mine)))
+    dfs = [pipeline.DiscreteFlow(H, W, device=dev, seed=rank) for _ in range(group)]
 
-    def compute(desc):
-        pair, backward = desc
-        img1, img2 = images[pair]
-        if backward:
-            img1, img2 = img2, img1
-        return df.run(img1, img2, a.bcd_times)
+    def compute_many(descs):
+        flows = []
+        for g0 in range(0, len(descs), group):
+            part = descs[g0:g0 + group]
+            for df, (pair, backward) in zip(dfs, part):
+                img1, img2 = images[pair]
+                if backward:
+                    img1, img2 = img2, img1
+                df.load_pair(img1, img2)
+                df.generisi()
+                df.nasumicni()
+            pipeline.ceoBCD_batch(dfs[:len(part)], a.bcd_times)
+            flows += [df.vratiKonacniFlow().clone() for df in dfs[:len(part)]]
+        return flows
 
-    flows = sharding.run_passes(passes, compute, world, rank, df.flow)
+    flows = sharding.run_passes(passes, None, world, rank, dfs[0].flow, compute_many=compute_many)
     if rank == 0:
         os.makedirs(a.out, exist_ok=True)
         for pair in range(a.pairs):

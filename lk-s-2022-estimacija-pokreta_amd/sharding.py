@@ -25,17 +25,27 @@ def gather_flows(flow, bufs, rank):
     return bufs
 
 
-def run_passes(passes, compute, world, rank, like):
+def run_passes(passes, compute, world, rank, like, compute_many=None):
     """Runs `compute(pass_descriptor) -> (H,W,2) tensor` for this rank's share of `passes` and gathers every
     result on rank 0.  Returns {pass index: tensor} on rank 0, {} elsewhere.  Ranks with fewer passes than
-    the longest share send a dummy field in the last round(s) so that every gather is collective."""
+    the longest share send a dummy field in the last round(s) so that every gather is collective.
+    `compute_many(list of descriptors) -> list of tensors`, if given, computes the rank's whole share at once (the GPU
+    driver batches the BCD sweeps of a rank's passes into shared launches); results and gathers are the same."""
     mine = assign_passes(len(passes), world, rank)
     rounds = (len(passes) + world - 1) // world
     bufs = make_gather_buffers(like, world, rank) if world > 1 else None
+    done = None
+    if compute_many is not None:
+        done = [f.clone() for f in compute_many([passes[i] for i in mine])]
     out = {}
     for r in range(rounds):
         idx = mine[r] if r < len(mine) else None
-        flow = compute(passes[idx]) if idx is not None else torch.zeros_like(like)
+        if idx is None:
+            flow = torch.zeros_like(like)
+        elif done is not None:
+            flow = done[r]
+        else:
+            flow = compute(passes[idx])
         if world == 1:
             out[idx] = flow.clone()
             continue

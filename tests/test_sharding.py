@@ -29,7 +29,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, npasses, outdir):
+def _worker(rank, world, port, npasses, outdir, many=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -49,7 +49,11 @@ def _worker(rank, world, port, npasses, outdir):
         return torch.from_numpy(O.full_pass(p, a, b, 1)["flows"][-1].astype(np.float32))
 
     passes = [(i // 2, i % 2) for i in range(npasses)]
-    got = sh.run_passes(passes, compute, world, rank, torch.empty((H, W, 2), dtype=torch.float32))
+    like = torch.empty((H, W, 2), dtype=torch.float32)
+    if many:      # the rank's whole share at once, as the GPU driver does to batch the BCD sweeps of its passes
+        got = sh.run_passes(passes, None, world, rank, like, compute_many=lambda ds: [compute(d) for d in ds])
+    else:
+        got = sh.run_passes(passes, compute, world, rank, like)
     if rank == 0:
         assert sorted(got) == list(range(npasses))
         for i, d in enumerate(passes):
@@ -61,7 +65,7 @@ def _worker(rank, world, port, npasses, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("npasses", [4, 3])
-def test_run_passes_gloo_world2(tmp_path, oracle, npasses):
-    mp.spawn(_worker, args=(2, _free_port(), npasses, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("npasses,many", [(4, False), (3, False), (5, True)])
+def test_run_passes_gloo_world2(tmp_path, oracle, npasses, many):
+    mp.spawn(_worker, args=(2, _free_port(), npasses, str(tmp_path), many), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
