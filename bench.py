@@ -435,10 +435,22 @@ def worker(args):
     # exercises the same RCCL gather path; a plain `python bench.py` runs without torch.distributed
     use_dist = "RANK" in os.environ
     if use_dist:
-        if eng.backend == "nccl":
-            dist.init_process_group("nccl", device_id=eng.dev)
-        else:
-            dist.init_process_group("gloo")
+        # the communication libraries print banners (RCCL: version / host, gloo: connection lines) on STDOUT when the first
+        # communicator comes up; stdout must carry the JSON line only, so fd 1 points at stderr until that has happened
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if eng.backend == "nccl":
+                dist.init_process_group("nccl", device_id=eng.dev)
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+            eng.sync()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         bufs = [sharding.make_gather_buffers(eng.like(), world, rank) for _ in range(eng.P)]
         eng.gather = lambda flow, slot: sharding.gather_flows(flow, bufs[slot], rank)
 

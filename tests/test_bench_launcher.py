@@ -42,5 +42,7 @@ def test_bench_single_rank_under_external_launcher_env():
     out = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--stub"],
                env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])   # gloo may print a connection line
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout          # the communication library's banner must not reach stdout
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 2
