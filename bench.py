@@ -239,6 +239,15 @@ def pmc_traffic(kernel, grids=None):
 
 
 # ---------------------------------------------------------------------------------------------------- engines
+def _device_and_backend(args, local_rank):
+    """Normally rank r drives GPU r over RCCL ("nccl").  --rehearse-on-one-gpu puts every rank on device 0 and gathers
+    over gloo: RCCL cannot host two ranks on one device, and the development box has one GPU; the launcher, the engines and
+    the torch.distributed calls are the same (tests/test_gpu_parity.py::test_bench_two_ranks_rehearsal)."""
+    if args.rehearse_on_one_gpu:
+        return 0, "gloo"
+    return local_rank, "nccl"
+
+
 class GpuEngine:
     """`inflight` independent pipelines per GPU: consecutive steps (= different image pairs) run on different HIP
     streams, so the latency-bound BCD chains of one pair overlap the MFMA-bound kNN screening of the next.  Every step is
@@ -249,9 +258,9 @@ class GpuEngine:
         self.torch = torch
         self.synth = importlib.import_module(PKG + ".synth")
         self.pipeline = importlib.import_module(PKG + ".pipeline")
+        local_rank, self.backend = _device_and_backend(args, local_rank)
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
-        self.backend = "nccl"
         self.rank = rank
         self.cellh, self.cellw = self.pipeline.default_cells(H, W)
         self.P = max(1, min(args.inflight, args.steps))
@@ -310,9 +319,9 @@ class BatchEngine:
         self.torch = torch
         self.synth = importlib.import_module(PKG + ".synth")
         self.pipeline = importlib.import_module(PKG + ".pipeline")
+        local_rank, self.backend = _device_and_backend(args, local_rank)
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
-        self.backend = "nccl"
         self.rank = rank
         self.cellh, self.cellw = self.pipeline.default_cells(H, W)
         self.B = max(1, args.batch)
@@ -484,7 +493,7 @@ def worker(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "stub" if args.stub else "synthetic",
+            "dtype": "f64", "data": "stub" if args.stub else ("synthetic (rehearsal: all ranks on one GPU)" if args.rehearse_on_one_gpu else "synthetic"),
         }
         if not args.stub:
             finish_report(out, eng, args, world)
@@ -551,6 +560,8 @@ def main():
                     help="streams: --inflight independent pipelines; batch: groups of --batch pairs share the BCD launches")
     ap.add_argument("--batch", type=int, default=8, help="pairs per group in --mode batch")
     ap.add_argument("--front", type=int, default=3, help="HIP streams for the front end of a group in --mode batch")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="all ranks on device 0, gather over gloo (a multi-rank rehearsal on a one-GPU box; not a measurement)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:

@@ -563,3 +563,21 @@ def test_bench_contract(torch_, tmp_path):
     assert len(c["entries"]) == 3 and c["entries"][2]["threads"] == 1 and "1241x375" in c["entries"][1]["config"]
     assert d["epe_delta_vs_oracle"] == 0.0 and d["epe"]["flow_fields_identical"] is True
     assert d["epe"]["gpu"]["all_pixels"] == d["epe"]["oracle"]["all_pixels"]
+
+
+def test_bench_two_ranks_rehearsal(torch_, tmp_path):
+    """`python bench.py --gpus 2` end to end on the one-GPU box: the launcher starts two ranks, both drive device 0
+    (--rehearse-on-one-gpu: gloo instead of RCCL, which cannot host two ranks on one device) through the batch engine, the
+    flow fields are gathered on rank 0 after every step, rank 0 prints ONE JSON line with n_gpus = 2."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--batch", "2", "--front", "2", "--no-cpu-baseline", "--rehearse-on-one-gpu"],
+                         capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 436 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["config"]["mode"] == "batch" and d["roofline"]["kernel"] == "bcd_chain_kernel"
