@@ -97,10 +97,10 @@ int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, cons
                               float *d_lcosts, int32_t *d_nprop, const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes,
                               void *stream)
 {
-    (void)d_ws; (void)ws_bytes;
     int rc = dflow_check_params(p); if (rc) return rc;
     CHECK_PTR(d_descr1); CHECK_PTR(d_descr2); CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels);
-    return launch_neighbour(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, (hipStream_t)stream);
+    CHECK_WS(neighbour_ws_bytes(p));
+    return launch_neighbour(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, d_ws, (hipStream_t)stream);
 }
 
 int dflow_bcd_prepare(const dflow_params *p, const uint32_t *d_proposals, const float *d_lcosts, const int32_t *d_nprop,

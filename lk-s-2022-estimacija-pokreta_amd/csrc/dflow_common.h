@@ -95,7 +95,8 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
 size_t knn_mfma_ws_bytes(const dflow_params *p);
 bool knn_mfma_supported(const dflow_params *p);
 int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
-                     int32_t *nprop, const int32_t *bestlabels, hipStream_t s);
+                     int32_t *nprop, const int32_t *bestlabels, void *ws, hipStream_t s);
+size_t neighbour_ws_bytes(const dflow_params *p);
 int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, int32_t *bestlabels, int phase,
                      void *ws, hipStream_t s);
 int launch_bcd_phase_batch(const dflow_params *p, int npass, const int32_t *const *nprop, int32_t *const *bestlabels, int phase,
