@@ -86,7 +86,8 @@ int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const floa
                         void *d_ws, size_t ws_bytes, void *stream);
 
 /* nasumicni, daisy i flann.py:205-233: appends up to ngauss neighbour proposals per pixel (in place).
- * d_bestlabels must still hold the WTA labels written by dflow_knn_proposals. */
+ * d_bestlabels must still hold the WTA labels written by dflow_knn_proposals.  Uses 4 bytes per pixel of the workspace
+ * (the WTA flow of every pixel, gathered once). */
 int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2,
                               uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop,
                               const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream);
