@@ -127,24 +127,23 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < BCD_MASK_WORDS; j++) { w[j] = tl < tn ? ~m[grp][j] : 0u; cnt += __popc(w[j]); }
-        uint32_t l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu, l2 = 0xFFFFFFFFu, l3 = 0xFFFFFFFFu, p0 = 0u, p1 = 0u;
+        uint32_t l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu, l2 = 0xFFFFFFFFu, l3 = 0xFFFFFFFFu;
         int n = 0;
         const uint32_t me = fcv[grp];
         if (64 * grp < tn) {                                 // wave-uniform
+            // (only the member indices inside the loop: the wave runs it as often as its longest list needs)
 #pragma unroll
             for (int j = 0; j < BCD_MASK_WORDS; j++) {
                 uint32_t ww = w[j];
                 while (ww && n < BCD_LIST) {
                     const uint32_t k = 32 * j + __ffs(ww) - 1; ww &= ww - 1;
-                    const uint32_t psi = flow_l1_biased(me, s_cols[wv][k]);
                     l0 = __builtin_amdgcn_alignbit(l1, l0, 8); l1 = __builtin_amdgcn_alignbit(l2, l1, 8);
                     l2 = __builtin_amdgcn_alignbit(l3, l2, 8); l3 = __builtin_amdgcn_alignbit(k, l3, 8);
-                    p0 = __builtin_amdgcn_alignbit(p1, p0, 4); p1 = __builtin_amdgcn_alignbit(psi, p1, 4);
                     n++;
                 }
             }
         }
-        // n entries sit in the top n bytes / nibbles: shift right by 16-n places, 0xFF / 0 come in from the top
+        // n entries sit in the top n bytes: shift right by 16-n places, 0xFF comes in from the top
         {
             const int sh = 16 - n;                            // 1..16
             if (sh & 1) { l0 = __builtin_amdgcn_alignbit(l1, l0, 8); l1 = __builtin_amdgcn_alignbit(l2, l1, 8);
@@ -154,9 +153,18 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
             if (sh & 4) { l0 = l1; l1 = l2; l2 = l3; l3 = 0xFFFFFFFFu; }
             if (sh & 8) { l0 = l2; l1 = l3; l2 = 0xFFFFFFFFu; l3 = 0xFFFFFFFFu; }
             if (sh & 16) { l0 = l1 = l2 = l3 = 0xFFFFFFFFu; }
-            unsigned long long pp = ((unsigned long long)p1 << 32) | p0;
-            pp = n ? pp >> (4 * sh) : 0ull;
-            p0 = (uint32_t)pp; p1 = (uint32_t)(pp >> 32);
+        }
+        // the members' pair costs, all at once (4 instructions per slot; in the loop they cost 5 per iteration of the
+        // longest list): |dy-dy'| + |dx-dx'| against the member's flow; empty slots (0xFF) read a valid word and are zeroed
+        uint32_t p0 = 0u, p1 = 0u;
+        if (64 * grp < tn) {
+#pragma unroll
+            for (int e = 0; e < BCD_LIST; e++) {
+                const uint32_t word = e < 4 ? l0 : (e < 8 ? l1 : (e < 12 ? l2 : l3));
+                const uint32_t k = (word >> (8 * (e & 3))) & 0xFFu;
+                const uint32_t psi = e < n ? flow_l1_biased(me, s_cols[wv][min(k, 191u)]) : 0u;    // k < 160, or 0xFF (empty slot) -> 191: inside the row
+                if (e < 8) p0 |= psi << (4 * e); else p1 |= psi << (4 * (e - 8));
+            }
         }
         // bytes 0..3 | 4, 5..8 | 9, 10..13 | 14 and nibbles 0..4, 5..9, 10..14 -> the three blocks
         const unsigned long long pp = ((unsigned long long)p1 << 32) | p0;
