@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
                                                         BcdPlanes pl)
 {
     __shared__ uint32_t s_cols[4][192];                      // the predecessor's biased labels, per wave
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[4][64][16];   // member lists being built, per wave and lane
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long item = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv);
     if (item >= 2LL * H * W) return;
@@ -127,33 +128,25 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < BCD_MASK_WORDS; j++) { w[j] = tl < tn ? ~m[grp][j] : 0u; cnt += __popc(w[j]); }
-        uint32_t l0 = 0xFFFFFFFFu, l1 = 0xFFFFFFFFu, l2 = 0xFFFFFFFFu, l3 = 0xFFFFFFFFu;
-        int n = 0;
+        // the first 15 members as bytes: every lane appends to its 16-byte row in LDS (one ds_write_b8 and a pointer
+        // increment per member; a shift register in VGPRs costs four instructions per member of the wave's LONGEST list) and
+        // reads the row back in place
+        uint8_t *row = &s_list[wv][lane][0];
+        *reinterpret_cast<uint4 *>(row) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         const uint32_t me = fcv[grp];
+        int n = 0;
         if (64 * grp < tn) {                                 // wave-uniform
-            // (only the member indices inside the loop: the wave runs it as often as its longest list needs)
 #pragma unroll
             for (int j = 0; j < BCD_MASK_WORDS; j++) {
                 uint32_t ww = w[j];
                 while (ww && n < BCD_LIST) {
-                    const uint32_t k = 32 * j + __ffs(ww) - 1; ww &= ww - 1;
-                    l0 = __builtin_amdgcn_alignbit(l1, l0, 8); l1 = __builtin_amdgcn_alignbit(l2, l1, 8);
-                    l2 = __builtin_amdgcn_alignbit(l3, l2, 8); l3 = __builtin_amdgcn_alignbit(k, l3, 8);
+                    row[n] = (uint8_t)(32 * j + __ffs(ww) - 1); ww &= ww - 1;
                     n++;
                 }
             }
         }
-        // n entries sit in the top n bytes: shift right by 16-n places, 0xFF comes in from the top
-        {
-            const int sh = 16 - n;                            // 1..16
-            if (sh & 1) { l0 = __builtin_amdgcn_alignbit(l1, l0, 8); l1 = __builtin_amdgcn_alignbit(l2, l1, 8);
-                          l2 = __builtin_amdgcn_alignbit(l3, l2, 8); l3 = __builtin_amdgcn_alignbit(0xFFFFFFFFu, l3, 8); }
-            if (sh & 2) { l0 = __builtin_amdgcn_alignbit(l1, l0, 16); l1 = __builtin_amdgcn_alignbit(l2, l1, 16);
-                          l2 = __builtin_amdgcn_alignbit(l3, l2, 16); l3 = __builtin_amdgcn_alignbit(0xFFFFFFFFu, l3, 16); }
-            if (sh & 4) { l0 = l1; l1 = l2; l2 = l3; l3 = 0xFFFFFFFFu; }
-            if (sh & 8) { l0 = l2; l1 = l3; l2 = 0xFFFFFFFFu; l3 = 0xFFFFFFFFu; }
-            if (sh & 16) { l0 = l1 = l2 = l3 = 0xFFFFFFFFu; }
-        }
+        const uint4 lst = *reinterpret_cast<const uint4 *>(row);
+        const uint32_t l0 = lst.x, l1 = lst.y, l2 = lst.z, l3 = lst.w;
         // the members' pair costs, all at once (4 instructions per slot; in the loop they cost 5 per iteration of the
         // longest list): |dy-dy'| + |dx-dx'| against the member's flow; empty slots (0xFF) read a valid word and are zeroed
         uint32_t p0 = 0u, p1 = 0u;
