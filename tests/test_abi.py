@@ -65,6 +65,21 @@ def test_null_pointers_are_rejected_before_any_launch(L):
     assert rc == -2 and b"workspace" in lib.dflow_last_error()
 
 
+def test_batched_entry_points_validate_on_the_host(L):
+    """dflow_bcd_*_batch take host arrays of device pointers: count, phase, NULL entries and the workspace size are
+    checked before anything is launched."""
+    lib = L.lib()
+    p = L.default_params(64, 64, 8, 8)
+    ws = lib.dflow_workspace_bytes(C.byref(p))
+    arr = (C.c_void_p * 2)(1, 1)
+    bad = (C.c_void_p * 2)(1, None)
+    assert lib.dflow_bcd_phase_batch(C.byref(p), 0, arr, arr, 0, arr, ws, None) == -1 and b"npass" in lib.dflow_last_error()
+    assert lib.dflow_bcd_phase_batch(C.byref(p), 2, arr, arr, 4, arr, ws, None) == -1 and b"phase" in lib.dflow_last_error()
+    assert lib.dflow_bcd_phase_batch(C.byref(p), 2, arr, bad, 0, arr, ws, None) == -1 and b"NULL" in lib.dflow_last_error()
+    assert lib.dflow_bcd_sweep_batch(C.byref(p), 2, arr, arr, arr, 16, None) == -2 and b"workspace" in lib.dflow_last_error()
+    assert lib.dflow_bcd_phase_batch(C.byref(p), 2, None, arr, 0, arr, ws, None) == -1
+
+
 def test_no_cpu_fallback(L):
     import torch
     if torch.cuda.is_available():

@@ -581,3 +581,36 @@ def test_bench_two_ranks_rehearsal(torch_, tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 436 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     assert d["config"]["mode"] == "batch" and d["roofline"]["kernel"] == "bcd_chain_kernel"
+
+
+def test_cli_kitti_png_branch(torch_, oracle, synth, tmp_path, monkeypatch):
+    """The reference's own input path (daisy i flann.py:19-27,34-35,52-53): 8-bit PNGs under
+    ../data_scene_flow/training/image_2/0001<idx>_1{0,1}.png, cropped to 1241x375 at (0,0), cells 73x25; backward swaps the
+    two frames.  KITTI itself is absent, so the PNGs are a synthetic 1242x375 pair written with PIL; the files the CLI
+    writes must equal the oracle's state on the cropped frames (whole frame, 16 threads)."""
+    import runpy, sys, os
+    from PIL import Image
+    from conftest import ROOT, PKG
+    O = oracle
+    img1, img2, _ = synth.make_pair(375, 1242, seed=synth.pair_seed(6, 0))
+    d = tmp_path / "data_scene_flow" / "training" / "image_2"
+    d.mkdir(parents=True)
+    Image.fromarray(np.ascontiguousarray(img1[..., ::-1])).save(str(d / "000106_10.png"))     # BGR -> RGB on disk
+    Image.fromarray(np.ascontiguousarray(img2[..., ::-1])).save(str(d / "000106_11.png"))
+    work = tmp_path / "work"
+    work.mkdir()
+    monkeypatch.chdir(work)
+    monkeypatch.setattr(sys, "argv", ["daisy i flann.py", "6", "1", "1", "--seed", "5"])      # backward run
+    runpy.run_path(os.path.join(ROOT, PKG, "daisy i flann.py"), run_name="__main__")
+    a, b = img2[:375, :1241], img1[:375, :1241]                                               # backward: pic1 = _11, pic2 = _10
+    O.set_threads(16)
+    try:
+        p = O.make_params(375, 1241, 25, 73, seed=5)
+        ref = O.full_pass(p, np.ascontiguousarray(a), np.ascontiguousarray(b), 0)
+    finally:
+        O.set_threads(1)
+    prop = np.load("Daisy output slike 106 backward=1 proposals_nakon_gausa.npy")
+    assert prop.shape == (375, 1241, 150, 2) and prop.dtype == np.int64 and np.array_equal(prop, ref["proposals"])
+    assert np.array_equal(np.load("Daisy output slike 106 backward=1 lcosts_nakon_gausa.npy"), ref["lcosts"])
+    assert np.array_equal(np.load("Daisy output slike 106 backward=1 nprop.npy"), ref["nprop"])
+    assert np.array_equal(np.load("Gotova flow slika 106 backward=1 posle 00 BCD.npy"), ref["flows"][0])
