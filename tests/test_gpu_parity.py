@@ -614,3 +614,58 @@ def test_cli_kitti_png_branch(torch_, oracle, synth, tmp_path, monkeypatch):
     assert np.array_equal(np.load("Daisy output slike 106 backward=1 lcosts_nakon_gausa.npy"), ref["lcosts"])
     assert np.array_equal(np.load("Daisy output slike 106 backward=1 nprop.npy"), ref["nprop"])
     assert np.array_equal(np.load("Gotova flow slika 106 backward=1 posle 00 BCD.npy"), ref["flows"][0])
+
+
+@pytest.mark.parametrize("case", ("all_compatible", "ties", "sparse_labels", "mixed_lengths"))
+def test_bcd_adversarial_label_sets_match_oracle(torch_, oracle, case):
+    """Hand-made states uploaded in the reference's dtypes (ucitajSvePodatkeDoBCD path) that drive the chain kernel through
+    its rare branches: every label compatible with every label of the neighbour (150-member lists: second / third blocks
+    and the 160-bit rows for every label), exact cost ties everywhere (first-index rules, Q9-Q11), pixels with very few
+    labels next to full ones, and lists of every length 0..40 side by side.  Labels after every phase of two sweeps must
+    equal the oracle's."""
+    O = oracle
+    H, W, ch, cw = 40, 44, 8, 11
+    rng = np.random.default_rng({"all_compatible": 1, "ties": 2, "sparse_labels": 3, "mixed_lengths": 4}[case])
+    L = 150
+    proposals = np.full((H, W, L, 2), -1, np.int64)
+    lcosts = np.full((H, W, L), 1000.0, np.float64)
+    nprop = np.zeros((H, W), np.int64)
+    for y in range(H):
+        for x in range(W):
+            if case == "all_compatible":          # all flows inside a 3x3 box: |d|_1 <= 4 < tpsi for every pair
+                n = 150
+                f = rng.integers(-1, 2, size=(n, 2))
+                c = rng.uniform(0.0, 2.5, n).astype(np.float32)
+            elif case == "ties":                  # few distinct flows and costs: ties in every minimum
+                n = int(rng.integers(100, 151))
+                f = rng.integers(-6, 7, size=(n, 2)) * np.array([1, 2])
+                c = rng.choice(np.array([0.5, 1.0, 2.5], np.float32), n)
+            elif case == "sparse_labels":
+                n = int(rng.choice([1, 2, 5, 150]))
+                f = rng.integers(-30, 31, size=(n, 2))
+                c = rng.uniform(0.0, 2.5, n).astype(np.float32)
+            else:                                 # clusters of growing size: list lengths 0..40
+                n = 150
+                f = np.zeros((n, 2), np.int64)
+                k = 0; cl = 0
+                while k < n:
+                    m = min(n - k, cl % 41 + 1)
+                    f[k:k + m] = np.array([40 * (cl % 7) - 120, 30 * (cl // 7) - 60]) + rng.integers(-1, 2, size=(m, 2))
+                    k += m; cl += 1
+                c = rng.uniform(0.0, 2.5, n).astype(np.float32)
+            proposals[y, x, :n] = f
+            lcosts[y, x, :n] = c.astype(np.float64)
+            nprop[y, x] = n
+    bestlabels = np.zeros((H, W), np.int64)
+    for y in range(H):
+        for x in range(W):
+            bestlabels[y, x] = rng.integers(0, nprop[y, x])
+    df = make(H, W, ch, cw, seed=1)
+    p = O.make_params(H, W, ch, cw, seed=1)
+    df.set_host_state(proposals, lcosts, nprop, bestlabels)
+    bl = bestlabels.copy()
+    for sweep in range(2):
+        for phase in range(4):
+            df.bcd_phase(phase)
+            O.bcd_phase(p, proposals, lcosts, nprop, bl, phase)
+            assert np.array_equal(df.bestlabels.cpu().numpy(), bl), (case, sweep, phase)
