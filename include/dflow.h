@@ -42,6 +42,10 @@ extern "C" {
 #define DFLOW_FLAG_KNN_EXACT 1   /* dflow_knn_proposals: brute-force VALU search instead of the MFMA-screened one (same
                                     results bit for bit; the cross-check of the screen's error bound) */
 
+#define DFLOW_FLAG_DESCR_F16 8    /* dflow_daisy: descriptor values rounded to IEEE binary16 (round to nearest even) before they are
+                                    stored (as float32): BASELINE configs[4] "fp16 DAISY descriptors".  Everything downstream (exact
+                                    kNN, costs, BCD) then works on those values; the reference has no such mode (cv2 returns f32) */
+
 #define DFLOW_OK 0
 #define DFLOW_EINVAL (-1)        /* bad parameter / null pointer / unsupported geometry */
 #define DFLOW_ENOSPC (-2)        /* workspace too small */

@@ -44,7 +44,7 @@ int dflow_check_params(const dflow_params *p)
     if (p->tpsi < 1 || p->tpsi > 8) return dflow_set_error(DFLOW_EINVAL, "tpsi=%d outside [1,8]", p->tpsi);
     if (!(p->sigma > 0.0f) || p->sigma > 8.0f) return dflow_set_error(DFLOW_EINVAL, "sigma=%g outside (0,8]", (double)p->sigma);
     if (p->max_attempts < p->ngauss) return dflow_set_error(DFLOW_EINVAL, "max_attempts < ngauss");
-    if (p->flags & ~DFLOW_FLAG_KNN_EXACT) return dflow_set_error(DFLOW_EINVAL, "unknown flags 0x%x", (unsigned)p->flags);
+    if (p->flags & ~(DFLOW_FLAG_KNN_EXACT | DFLOW_FLAG_DESCR_F16)) return dflow_set_error(DFLOW_EINVAL, "unknown flags 0x%x", (unsigned)p->flags);
     return DFLOW_OK;
 }
 

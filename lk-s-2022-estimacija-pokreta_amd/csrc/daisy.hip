@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(BX * BY / 2) blur2d_kernel(const float4 *__res
 }
 
 // one thread = one (pixel, grid point): a coalesced float4 store into the 68-float descriptor row
-__global__ void gather_kernel(const float4 *__restrict__ cubes, float4 *__restrict__ descr, int H, int W, GridTab g)
+__global__ void gather_kernel(const float4 *__restrict__ cubes, float4 *__restrict__ descr, int H, int W, GridTab g, int f16)
 {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)H * W * 17;
@@ -145,6 +145,9 @@ __global__ void gather_kernel(const float4 *__restrict__ cubes, float4 *__restri
         out = tadd(out, tmul<float4>(w1, C));
         out = tadd(out, tmul<float4>(w2, B));
         out = tadd(out, tmul<float4>(w3, D));
+    }
+    if (f16) {   // DFLOW_FLAG_DESCR_F16: descriptor values rounded to binary16 (round to nearest even), kept in float32 storage
+        out.x = (float)(_Float16)out.x; out.y = (float)(_Float16)out.y; out.z = (float)(_Float16)out.z; out.w = (float)(_Float16)out.w;
     }
     descr[gid] = out;
 }
@@ -222,6 +225,6 @@ int launch_daisy(const dflow_params *p, const uint8_t *bgr, float *descr, void *
         }
     size_t total = N * 17;
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), blk, 0, s, (const float4 *)cubes,
-                       (float4 *)descr, H, W, g);
+                       (float4 *)descr, H, W, g, (p->flags & DFLOW_FLAG_DESCR_F16) ? 1 : 0);
     return dflow_check_launch("daisy kernels");
 }

@@ -11,7 +11,8 @@ The compat bit matrices (packedksets, 2.6 GB; with dopython=0 the four 'pakovani
 All computation runs in libdflow.so on the GPU; there is no CPU fallback.
 
 Options for inputs the reference cannot handle: --image1/--image2 PATH, --cell HxW, --synthetic HxW
-(synthetic pair with seed 1000*idx+backward), --seed N (neighbour-sampler key), --device cuda:N.
+(synthetic pair with seed 1000*idx+backward), --seed N (neighbour-sampler key), --device cuda:N,
+--fp16-descriptors (BASELINE configs[4]: DAISY values rounded to binary16).
 """
 import argparse
 import importlib
@@ -35,6 +36,7 @@ def main(argv=None):
     ap.add_argument("--image1"); ap.add_argument("--image2"); ap.add_argument("--cell"); ap.add_argument("--synthetic")
     ap.add_argument("--seed", type=int, default=0); ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--packedksets", action="store_true", help="also write the reference's compat-matrix file(s)")
+    ap.add_argument("--fp16-descriptors", action="store_true", help="round the DAISY values to binary16 (DFLOW_FLAG_DESCR_F16)")
     a = ap.parse_args(argv)
     pipeline = importlib.import_module(PKG + ".pipeline")
     flowio = importlib.import_module(PKG + ".flowio")
@@ -54,7 +56,8 @@ def main(argv=None):
             pic1, pic2 = pic1[:375, :1241], pic2[:375, :1241]
     pich, picw = pic1.shape[:2]
     cellh, cellw = (int(v) for v in a.cell.lower().split("x")) if a.cell else pipeline.default_cells(pich, picw)
-    df = pipeline.DiscreteFlow(pich, picw, cellh, cellw, device=a.device, seed=a.seed)
+    flags = importlib.import_module(PKG + "._lib").FLAG_DESCR_F16 if a.fp16_descriptors else 0
+    df = pipeline.DiscreteFlow(pich, picw, cellh, cellw, device=a.device, seed=a.seed, flags=flags)
     df.load_pair(np.ascontiguousarray(pic1), np.ascontiguousarray(pic2))    # :406-407
     df.generisi()                                                           # :409-412
     flow0 = df.vratiKonacniFlow().cpu().numpy().astype(np.float64)

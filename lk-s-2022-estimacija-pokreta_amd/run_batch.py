@@ -28,6 +28,8 @@ def main(argv=None):
     ap.add_argument("--thresh", type=float, default=10.0)     # README.md:65 of the reference
     ap.add_argument("--out", default=".")
     ap.add_argument("--group", type=int, default=4, help="passes of a rank whose BCD sweeps share their launches")
+    ap.add_argument("--cell", default=None, help="cell size HxW (default: the geometry's usual cells)")
+    ap.add_argument("--fp16-descriptors", action="store_true", help="DAISY values rounded to binary16 (BASELINE configs[4])")
     a = ap.parse_args(argv)
     import torch
     import torch.distributed as dist
@@ -53,7 +55,9 @@ def main(argv=None):
     # the passes of a rank (forward and backward runs, several pairs) are independent: their front ends run one after the
     # other, their BCD sweeps as batched launches (dflow_bcd_sweep_batch), `group` passes at a time
     group = max(1, min(a.group, len(mine)))
-    dfs = [pipeline.DiscreteFlow(H, W, device=dev, seed=rank) for _ in range(group)]
+    flags = importlib.import_module(PKG + "._lib").FLAG_DESCR_F16 if a.fp16_descriptors else 0
+    ch, cw = (int(v) for v in a.cell.lower().split("x")) if a.cell else (None, None)
+    dfs = [pipeline.DiscreteFlow(H, W, ch, cw, device=dev, seed=rank, flags=flags) for _ in range(group)]
 
     def compute_many(descs):
         flows = []

@@ -47,7 +47,7 @@ def test_workspace_size_and_validation(L):
     assert ws > 436 * 1024 * 2 * 160 * 20                 # at least the BCD bit matrices
     for field, bad, msg in (("knn", 4, b"knn"), ("window", 3, b"window"), ("maxnprop", 200, b"maxnprop"),
                             ("label_pitch", 150, b"label_pitch"), ("cellh", 0, b"cell"), ("pich", 4, b"image size"),
-                            ("tpsi", 0, b"tpsi"), ("ngauss", 100, b"ngauss"), ("flags", 64, b"flags")):
+                            ("tpsi", 0, b"tpsi"), ("ngauss", 100, b"ngauss"), ("flags", 64, b"flags"), ("flags", 2, b"flags")):
         q = L.default_params(436, 1024, 27, 64)
         setattr(q, field, bad)
         assert lib.dflow_workspace_bytes(C.byref(q)) == 0

@@ -669,3 +669,33 @@ def test_bcd_adversarial_label_sets_match_oracle(torch_, oracle, case):
             df.bcd_phase(phase)
             O.bcd_phase(p, proposals, lcosts, nprop, bl, phase)
             assert np.array_equal(df.bestlabels.cpu().numpy(), bl), (case, sweep, phase)
+
+
+def test_fp16_descriptor_mode_matches_oracle(torch_, oracle, synth):
+    """BASELINE configs[4] names "fp16 DAISY descriptors": DFLOW_FLAG_DESCR_F16 rounds every descriptor value to binary16
+    (values stay in float32 storage).  DAISY must equal the oracle's descriptors rounded the same way (numpy float16, round
+    to nearest even), and the rest of the path (MFMA-screened exact kNN, costs, neighbour stage, two sweeps) must equal the
+    oracle run on those rounded descriptors."""
+    O = oracle
+    L = pkg("_lib")
+    H, W, ch, cw = 60, 84, 10, 12
+    img1, img2, _ = synth.make_pair(H, W, seed=31, amp_x=7.0, amp_y=5.0)
+    df = make(H, W, ch, cw, seed=9)
+    df.p.flags = L.FLAG_DESCR_F16
+    p = O.make_params(H, W, ch, cw, seed=9)
+    df.load_pair(img1, img2)
+    d1 = O.daisy(img1).astype(np.float16).astype(np.float32)
+    d2 = O.daisy(img2).astype(np.float16).astype(np.float32)
+    assert np.array_equal(df.descrs1.cpu().numpy().view(np.uint32), d1.view(np.uint32))
+    assert np.array_equal(df.descrs2.cpu().numpy().view(np.uint32), d2.view(np.uint32))
+    assert not np.array_equal(d1, O.daisy(img1))                     # the mode does change the values
+    df.generisi()
+    pr, lc, npr, bl = O.knn_proposals(p, d1, d2)
+    df.nasumicni()
+    O.neighbour_proposals(p, d1, d2, pr, lc, npr, bl)
+    st = df.host_state()
+    assert np.array_equal(st["nprop"], npr) and np.array_equal(st["proposals"], pr) and np.array_equal(st["lcosts"], lc)
+    for sweep in range(2):
+        df.ceoBCD(1)
+        O.bcd_sweep(p, pr, lc, npr, bl)
+        assert np.array_equal(df.bestlabels.cpu().numpy(), bl), sweep
