@@ -551,8 +551,8 @@ def finish_report(out, eng, args, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=96)       # 12 groups of 8: the fill and drain of the two-group pipeline weigh < 10 %
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent pairs in flight per GPU (each on its own HIP stream and workspace)")
