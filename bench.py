@@ -221,19 +221,25 @@ def stage_rooflines(torch, df, pair, cellh, cellw, reps=3):
     }
 
 
-def pmc_traffic(kernel, grids=None):
+def pmc_traffic(kernel, unit_grids=None, passes=1.0):
     """HBM bytes per launch of `kernel` from the tracked rocprofv3 --pmc summary (profiles/pmc_traffic.json, written by
-    scratch/pmc_to_json.py from separate FETCH_SIZE and WRITE_SIZE passes of this command; FETCH_SIZE already doubled as
-    MI355X_MICROARCH.md prescribes for gfx950's wide reads).  `grids` = launch sizes in threads to average over (the
-    profiled command also launches the kernel in other geometries); None if the file has no matching entry."""
+    scratch/pmc_to_json.py from separate FETCH_SIZE and WRITE_SIZE passes of the bench command; FETCH_SIZE already doubled as
+    MI355X_MICROARCH.md prescribes for gfx950's wide reads).  `unit_grids` = launch sizes in threads of ONE pass (column and
+    row phases); a batched launch carries `passes` of them and moves that many times the bytes (every pass streams its own
+    planes), so the per-pass traffic of every profiled multiple of a unit grid is averaged and scaled.  None if the file has
+    no matching entry."""
     try:
         with open(PMC_TRAFFIC_FILE) as f:
             d = json.load(f)
         e = d["kernels"][kernel]
-        if grids:
-            v = [e["by_grid_threads"][str(g)]["hbm_bytes_per_launch"] for g in grids]
-            return int(sum(v) / len(v)), d.get("source", PMC_TRAFFIC_FILE)
-        return int(e["hbm_bytes_per_launch"]), d.get("source", PMC_TRAFFIC_FILE)
+        if not unit_grids:
+            return int(e["hbm_bytes_per_launch"]), d.get("source", PMC_TRAFFIC_FILE)
+        per_unit = []
+        for u in unit_grids:
+            v = [(g["hbm_bytes_per_launch"] / (int(k) // u), g["launches_in_pass"]) for k, g in e["by_grid_threads"].items()
+                 if int(k) % u == 0 and int(k) // u >= 1]
+            per_unit.append(sum(a * n for a, n in v) / sum(n for _, n in v))
+        return int(passes * sum(per_unit) / len(per_unit)), d.get("source", PMC_TRAFFIC_FILE) + " (per pass, scaled to the passes of a launch)"
     except Exception:
         return None, None
 
@@ -348,11 +354,13 @@ class BatchEngine:
 
     def begin(self, nsteps):
         self.pending, self.nsteps, self.done = [], nsteps, 0
+        ngroups = max(1, -(-nsteps // self.B))              # groups of equal size, at most `batch` pairs each
+        self.Bcur = max(1, -(-nsteps // ngroups))
 
     def step(self, i, timed):
         self.pending.append(i)
         self.done += 1
-        if len(self.pending) == self.B or self.done == self.nsteps:
+        if len(self.pending) == self.Bcur or self.done == self.nsteps:
             self._run_group(self.pending, timed)
             self.pending = []
 
@@ -509,7 +517,7 @@ def finish_report(out, eng, args, world):
     out["config"] = {"workload": "single 1024x436 Sintel-shape pair per step per GPU, forward only, bcd_times=4 "
                                  "(BASELINE.json configs[1]); cells 64x27, 150 labels/px",
                      "pairs_in_flight_per_gpu": P, "pair_seeds_rank0": eng.seeds, "mode": args.mode,
-                     "parallelism": ("one pass per step, steps in groups of %d: front end of a group's pairs on %d HIP streams, the "
+                     "parallelism": ("one pass per step, steps in equal groups of at most %d: front end of a group's pairs on %d HIP streams, the "
                                      "BCD sweeps of the group as one batched launch per phase (chains x passes), two groups "
                                      "alternate so that front end and sweeps of consecutive groups overlap; flow fields gathered "
                                      "on rank 0" % (P, args.front)) if args.mode == "batch" else
@@ -526,8 +534,7 @@ def finish_report(out, eng, args, world):
     achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
     # the launches of the timed region: column phases (W+1)//2 resp. W//2 chains, row phases (H+1)//2 resp. H//2 chains,
     # 192 threads per chain, times the passes of a group
-    ppl = int(round(passes_per_launch))
-    traffic, traffic_src = pmc_traffic("bcd_chain_kernel", [((W + 1) // 2) * 192 * ppl, ((H + 1) // 2) * 192 * ppl])
+    traffic, traffic_src = pmc_traffic("bcd_chain_kernel", [((W + 1) // 2) * 192, ((H + 1) // 2) * 192], passes_per_launch)
     out["roofline"] = {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "traffic": traffic, "traffic_source": traffic_src,
@@ -558,7 +565,8 @@ def main():
                     help="independent pairs in flight per GPU (each on its own HIP stream and workspace)")
     ap.add_argument("--mode", choices=("streams", "batch"), default="batch",
                     help="streams: --inflight independent pipelines; batch: groups of --batch pairs share the BCD launches")
-    ap.add_argument("--batch", type=int, default=8, help="pairs per group in --mode batch")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="largest group in --mode batch (the steps are split into equal groups of at most this many pairs)")
     ap.add_argument("--front", type=int, default=3, help="HIP streams for the front end of a group in --mode batch")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks on device 0, gather over gloo (a multi-rank rehearsal on a one-GPU box; not a measurement)")
