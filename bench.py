@@ -332,6 +332,9 @@ class BatchEngine:
         self.cellh, self.cellw = self.pipeline.default_cells(H, W)
         self.B = max(1, args.batch)
         self.P = self.B
+        self.groups = [int(x) for x in args.groups.split(",")] if getattr(args, "groups", None) else None
+        if self.groups and max(self.groups) > self.B:
+            raise SystemExit("--groups: a group cannot exceed --batch")
         self.sets = [[self.pipeline.DiscreteFlow(H, W, self.cellh, self.cellw, device=self.dev, seed=rank) for _ in range(self.B)]
                      for _ in range(2)]
         self.flows = self.sets[0]
@@ -354,15 +357,21 @@ class BatchEngine:
 
     def begin(self, nsteps):
         self.pending, self.nsteps, self.done = [], nsteps, 0
-        ngroups = max(1, -(-nsteps // self.B))              # groups of equal size, at most `batch` pairs each
-        self.Bcur = max(1, -(-nsteps // ngroups))
+        if self.groups and sum(self.groups) == nsteps:
+            self.plan = list(self.groups)
+        else:
+            ngroups = max(1, -(-nsteps // self.B))          # groups of equal size, at most `batch` pairs each
+            q, r = divmod(nsteps, ngroups)
+            self.plan = [q + 1] * r + [q] * (ngroups - r)
+        self.plan_at = 0
 
     def step(self, i, timed):
         self.pending.append(i)
         self.done += 1
-        if len(self.pending) == self.Bcur or self.done == self.nsteps:
+        if len(self.pending) == self.plan[self.plan_at] or self.done == self.nsteps:
             self._run_group(self.pending, timed)
             self.pending = []
+            self.plan_at = min(self.plan_at + 1, len(self.plan) - 1)
 
     def _run_group(self, idx, timed):
         torch = self.torch
@@ -570,6 +579,7 @@ def main():
     ap.add_argument("--front", type=int, default=3, help="HIP streams for the front end of a group in --mode batch")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks on device 0, gather over gloo (a multi-rank rehearsal on a one-GPU box; not a measurement)")
+    ap.add_argument("--groups", default=None, help=argparse.SUPPRESS)    # experiment: explicit group sizes of the timed region
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:

@@ -600,6 +600,192 @@ __global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve
     }
 }
 
+#ifndef KM_RESOLVE_V1
+// ------------------------------------------------------------------------------------------------ resolve, staged rows
+// knn_resolve_kernel (above, kept for A/B runs: -DKM_RESOLVE_V1) is bound by the L1's access rate: every lane fetches its
+// query row and each candidate row with 17 dwordx4 loads = 17 cache accesses per row (TCP_TOTAL_CACHE_ACCESSES = 1.1e9 per
+// launch, 0.94 per CU and cycle; 40 % of them for the query rows, which it fetches once per candidate cell).  Here
+//  * a wave keeps its 64 queries (lane = query: both half-lane lists of the query are pooled) over the window cells of
+//    one window column, so a query row is fetched once per 5 candidate cells;
+//  * the 64 rows of a round are fetched by the whole wave: one global_load_lds_dwordx4 covers 4 rows x 16 pieces of
+//    16 bytes (256 contiguous bytes per row = a few cache accesses instead of 16), straight into LDS; every lane then
+//    reads its own row back with ds_read_b128 (column g of LDS row r holds piece g ^ (r & 15): conflict free) and keeps
+//    it in registers, so the fetches of the next round overlap the arithmetic of this one.  The 17th piece of a row
+//    (bytes 256..271) is fetched by its own lane.
+// One wave per block.  The arithmetic per (query, candidate) pair is that of knn_resolve_kernel and the top 5 are ordered
+// by the same (distance, index) keys, so the results are identical.
+#define KM_EVLIST2 32            // candidates per query and candidate cell listed in LDS (more: exact redo by knn_fix_kernel)
+__global__ void __launch_bounds__(64, 2) knn_resolve2_kernel(KmGeom a, KmResolve p)
+{
+    const Geom g = a.g;
+    const int lane = threadIdx.x, gq = lane >> 5, col = lane & 31;
+    const int win = 2 * g.win + 1;
+    int b = blockIdx.x;
+    const int qwave = b % a.qwaves; b /= a.qwaves;
+    const int cir = b % win; const int qcell = b / win;
+    const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
+    const int ci = qci - g.win + cir;
+    if (ci < 0 || ci >= g.ncx) return;
+    const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
+    if (qwave * KM_QPW >= qnpts) return;
+    const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
+    const int cx0 = g.x0(ci), ccw = g.x1(ci) - cx0;
+
+    __shared__ __attribute__((aligned(1024))) char stage[64 * 256];   // LDS row r: pieces 0..15 of lane r's row, swizzled
+    __shared__ uint16_t evl[KM_EVLIST2][64];                          // this query's candidate indices, [slot][lane]
+    __shared__ __attribute__((aligned(16))) uint32_t s_cand[64];      // row offsets (16-byte units) of the round, [lane & 3][lane >> 2]
+    const int sub = lane >> 4;
+    // piece fetched by this lane in instruction k (LDS row 4k + sub, column lane & 15): (lane & 15) ^ ((4k & 15) | sub)
+    const uint32_t pz0 = (uint32_t)((lane & 15) ^ sub);
+    const uint32_t rd0 = (uint32_t)(lane * 256 + ((lane & 15) << 4));   // own row: the column of piece j is at rd0 ^ (j << 4)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v tail_next = {0.f, 0.f, 0.f, 0.f};
+
+    // fetch of 64 rows (lane's row = 16-byte offset off16 from `base`; inactive lanes fetch nothing)
+    auto issue = [&](const __attribute__((address_space(1))) char *base, uint32_t off16, bool act) {
+        s_cand[(lane & 3) * 16 + (lane >> 2)] = act ? off16 : 0xFFFFFFFFu;
+        __syncthreads();
+        const uint4 *sc = reinterpret_cast<const uint4 *>(&s_cand[sub * 16]);
+        uint32_t cr[16];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) { const uint4 v = sc[k4]; cr[4 * k4] = v.x; cr[4 * k4 + 1] = v.y; cr[4 * k4 + 2] = v.z; cr[4 * k4 + 3] = v.w; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (cr[k] != 0xFFFFFFFFu) {
+                const uint32_t piece = pz0 ^ (uint32_t)((4 * k) & 15);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + ((unsigned long long)(cr[k] + piece) << 4)),
+                                                 (__attribute__((address_space(3))) void *)(stage + k * 1024), 16, 0, 0);
+            }
+        }
+        if (act) tail_next = *reinterpret_cast<const __attribute__((address_space(1))) f4v *>(base + ((unsigned long long)(off16 + 16u) << 4));
+    };
+    auto fetch_rows = [&](float4 (&cv)[17]) {            // the staged rows -> registers (the stage buffer is free afterwards)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) cv[j] = *reinterpret_cast<const float4 *>(stage + (rd0 ^ (uint32_t)(j << 4)));
+        cv[16] = make_float4(tail_next.x, tail_next.y, tail_next.z, tail_next.w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // ---- the queries of this wave
+    float q[DFLOW_DESC];
+    int qi = qwave * KM_QPW + lane;
+    const bool qvalid = qi < qnpts;
+    if (!qvalid) qi = qnpts - 1;
+    const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
+    const size_t qpix = (size_t)qy * g.W + qx;
+    {
+        issue((const __attribute__((address_space(1))) char *)p.d1, (uint32_t)qpix * 17u, true);
+        float4 qv[17];
+        fetch_rows(qv);
+#pragma unroll
+        for (int k = 0; k < 17; k++) { q[4 * k] = qv[k].x; q[4 * k + 1] = qv[k].y; q[4 * k + 2] = qv[k].z; q[4 * k + 3] = qv[k].w; }
+    }
+    const __attribute__((address_space(1))) char *d2g = (const __attribute__((address_space(1))) char *)p.d2;
+
+    for (int cj = cjmin; cj <= cjmax; cj++) {
+        const int wslot = (ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin);   // reference order: ci outer, cj inner (Q2)
+        const size_t lid = list_id(a, qcell, qwave, wslot);
+        const int cy0 = g.y0(cj);
+        const int ntiles = (ccw * (g.y1(cj) - cy0) + KM_CHUNK - 1) / KM_CHUNK * (KM_CHUNK / 32);   // as in the screen kernel
+        // the query's events: list of half-lane 0 (tile rows 0..3, 8..11, ...) and of half-lane 1 (rows 4..7, 12..15, ...)
+        const int nA = p.ev_cnt[(size_t)lid * 128 + gq * 64 + col], nB = p.ev_cnt[(size_t)lid * 128 + gq * 64 + col + 32];
+        bool ovf = nA == 255 || nB == 255;
+        const uint32_t *evA = p.ev + (size_t)lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + col;
+        uint32_t entA[4], entB[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { entA[e] = e < nA && !ovf ? evA[e * 64] : 0u; entB[e] = e < nB && !ovf ? evA[e * 64 + 32] : 0u; }   // the first entries are fetched together
+        int nev = 0;
+        auto expand = [&](uint32_t entry, int h) {
+            const int tile = (int)(entry >> 16);
+            uint32_t mask = entry & 0xFFFFu;
+            while (mask) {
+                const int r = __ffs(mask) - 1;
+                mask &= mask - 1;
+                // accumulator register r of half-lane h = tile row 4 h + (r & 3) + 8 (r >> 2) = candidate row * ntiles + tile
+                if (nev < KM_EVLIST2) evl[nev][lane] = (uint16_t)((4 * h + (r & 3) + 8 * (r >> 2)) * ntiles + tile);
+                nev++;
+            }
+        };
+        if (!ovf) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) expand(entA[e], 0);
+            for (int e = 4; e < nA; e++) expand(evA[e * 64], 0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) expand(entB[e], 1);
+            for (int e = 4; e < nB; e++) expand(evA[e * 64 + 32], 1);
+        }
+        ovf |= nev > KM_EVLIST2;
+        if (__ballot(ovf)) {                             // out of list space somewhere: exact redo of this list by knn_fix_kernel
+            if (lane == 0) {
+                int pos = atomicAdd(p.ovf_count, 1);
+                if (pos < p.ovf_cap) p.ovf_list[pos] = make_int4(qcell, qwave * KM_QPW, ci, cj);
+            }
+            continue;
+        }
+        unsigned long long keys[5];
+        float costs[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { keys[i] = 0x7F800000FFFFFFFFull; costs[i] = 0.0f; }   // (+inf, no index)
+
+        auto issue_cand = [&](int e) -> int {
+            const bool act = e < nev;
+            const int idx = act ? evl[e][lane] : 0;
+            issue(d2g, (uint32_t)((cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * 17u, act);
+            return idx;
+        };
+        if (__ballot(nev > 0)) {
+            int e = 0;
+            int idx_next = issue_cand(0);
+            while (true) {
+                float4 cv[17];
+                fetch_rows(cv);
+                const bool act = e < nev;
+                const int idx = idx_next;
+                e++;
+                const bool more = __ballot(e < nev) != 0;
+                if (more) idx_next = issue_cand(e);
+                // ---- canonical distance (sequential fmaf chain) and L1 cost (numpy pairwise order), as in knn_resolve_kernel
+                const float worst = __uint_as_float((unsigned)(keys[4] >> 32));
+                float acc = 0.0f, rs[8], tl[4];
+#pragma unroll
+                for (int k = 0; k < 17; k++) {
+                    const float4 v = cv[k];
+                    const float e0 = q[4 * k] - v.x, e1 = q[4 * k + 1] - v.y, e2 = q[4 * k + 2] - v.z, e3 = q[4 * k + 3] - v.w;
+                    acc = __fmaf_rn(e0, e0, acc); acc = __fmaf_rn(e1, e1, acc);
+                    acc = __fmaf_rn(e2, e2, acc); acc = __fmaf_rn(e3, e3, acc);
+                    const int j = (4 * k) & 7;
+                    if (k < 2) { rs[j] = fabsf(e0); rs[j + 1] = fabsf(e1); rs[j + 2] = fabsf(e2); rs[j + 3] = fabsf(e3); }
+                    else if (k < 16) { rs[j] = rs[j] + fabsf(e0); rs[j + 1] = rs[j + 1] + fabsf(e1); rs[j + 2] = rs[j + 2] + fabsf(e2); rs[j + 3] = rs[j + 3] + fabsf(e3); }
+                    else { tl[0] = fabsf(e0); tl[1] = fabsf(e1); tl[2] = fabsf(e2); tl[3] = fabsf(e3); }
+                }
+                if (act && !(acc > worst)) {
+                    float l1 = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+                    l1 = l1 + tl[0]; l1 = l1 + tl[1]; l1 = l1 + tl[2]; l1 = l1 + tl[3];
+                    key_insert(keys, costs, ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)idx, l1);
+                }
+                if (!more) break;
+            }
+        }
+        // ---- emit (daisy i flann.py:174-180)
+        if (qvalid) {
+            const size_t pix = (size_t)qy * g.W + qx;
+            const int slot_base = 5 * wslot;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int idx = (int)(keys[j] & 0xFFFFFFFFu);
+                const float s = costs[j];
+                const int ty = cy0 + idx / ccw, tx = cx0 + idx % ccw;
+                p.proposals[pix * a.LP + slot_base + j] = pack_flow(ty - qy, tx - qx);
+                p.lcosts[pix * a.LP + slot_base + j] = s < a.tphi ? s : a.tphi;
+            }
+        }
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ finalize
 // nprop = 5 x window cells (daisy i flann.py:189), WTA label = first minimum of the costs with strict '<'
 // from 1000.0 (:93,181-184), fills beyond nprop (:89-90).  16 lanes per pixel: coalesced reads of the cost row,
@@ -706,7 +892,11 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     KmResolve rs;
     rs.d1 = d1; rs.d2 = d2; rs.ev = ev; rs.ev_cnt = ev_cnt; rs.proposals = proposals; rs.lcosts = lcosts;
     rs.ovf_count = ctr; rs.ovf_list = ovf; rs.ovf_cap = KM_OVF_CAP;
+#ifdef KM_RESOLVE_V1
     hipLaunchKernelGGL(knn_resolve_kernel, dim3((unsigned)(g.ncx * g.ncy * win * win * ((a.qwaves + 3) / 4))), dim3(256), 0, s, a, rs);
+#else
+    hipLaunchKernelGGL(knn_resolve2_kernel, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
+#endif
     rc = dflow_check_launch("knn_resolve_kernel");
     if (rc) return rc;
     rc = launch_knn_fix(p, d1, d2, proposals, lcosts, ctr, ovf, KM_OVF_CAP, ctr + 1, s);
