@@ -20,10 +20,10 @@
 //             v + S_q >= tau.  Only candidates with v >= a5 - 2 S_q - s (s: rounding of the canonical float32 distance)
 //             can be among the exact 5 NN: these "events" (a 16-bit row mask per lane and tile) go to per-lane lists in
 //             the workspace.
-//   resolve   (knn_resolve_kernel) one wave per event list: canonical float32 distance (sequential fmaf chain, with
-//             early exit once the partial sum exceeds the lane's 5th best) and truncated L1 cost (numpy order) of
-//             every event, exact (distance, index) top-5 in registers, proposals [dy,dx] and costs into the cell's
-//             5 slots (Q1-Q3).
+//   resolve   (knn_resolve_kernel) one wave per (64 queries, window column): canonical float32 distance (sequential
+//             fmaf chain) and truncated L1 cost (numpy order) of every event, exact (distance, index) top-5 in
+//             registers, proposals [dy,dx] and costs into the cell's 5 slots (Q1-Q3).  The rows are fetched by the
+//             whole wave through LDS (see the kernel).
 //   fix       lists that overflowed (or a pass with descriptors outside the f16 range / NaN) are redone by the exact
 //             brute-force search (knn.hip).  finalize sets nprop, the WTA label (first minimum, Q4) and the fills.
 //
@@ -50,7 +50,6 @@ template <int V> struct KmC { static constexpr int value = V; };
 #define KM_EVROWS 32            // event entries (tile, 16-bit row mask) per lane, group and candidate cell
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
 #define KM_LIST_WORDS (2 * KM_EVROWS * 64)       // one event list: [group][entry][lane] uint32
-#define KM_EVLIST 64             // candidates per lane and group the resolve kernel lists in LDS
 #define KM_T 1.7263349e-4f                       // t = 2^-12.5: split of the cross terms |q~||E_c|, |E_q||c| (see header)
 #define KM_ETA 2.44140625e-4f                    // eta = 2^-12: allowance for the f32 accumulation inside the matrix core
 #define KM_MEAN_SAMPLES 1024
@@ -456,155 +455,10 @@ __device__ static inline void key_insert(unsigned long long (&k)[5], float (&c)[
     }
 }
 
-// one wave per event list; lane = (query column lane&31, candidate half lane>>5), both groups in turn
-__global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve p)
-{
-    const Geom g = a.g;
-    const int lane = threadIdx.x & 63, half = lane >> 5;
-    // Candidate-cell-major order, like the screen kernel: the blocks in flight at any time gather rows of the same few
-    // candidate cells (470 KB each), which then stay in the XCDs' L2.  A block = 4 consecutive 64-query waves of one
-    // (candidate cell, query cell) pair.
-    const int win = 2 * g.win + 1;
-    const int qw4n = (a.qwaves + 3) / 4;
-    int b = blockIdx.x;
-    const int qwave = (b % qw4n) * 4 + (threadIdx.x >> 6); b /= qw4n;
-    const int qslot = b % (win * win); const int ccell = b / (win * win);
-    const int ci = ccell % g.ncx, cj = ccell / g.ncx;
-    const int qci = ci - g.win + qslot / win, qcj = cj - g.win + qslot % win;
-    if (qci < 0 || qci >= g.ncx || qcj < 0 || qcj >= g.ncy) return;
-    const int qcell = qcj * g.ncx + qci;
-    const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
-    if (qwave >= a.qwaves || qwave * KM_QPW >= qnpts) return;
-    const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
-    const int wslot = (ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin);   // reference order: ci outer, cj inner (Q2)
-    const size_t lid = list_id(a, qcell, qwave, wslot);
-    const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0;
-    const int ntiles = (ccw * (g.y1(cj) - cy0) + KM_CHUNK - 1) / KM_CHUNK * (KM_CHUNK / 32);   // as in the screen kernel
-
-    const int c0 = p.ev_cnt[(size_t)lid * 128 + lane], c1 = p.ev_cnt[(size_t)lid * 128 + 64 + lane];
-    if (__ballot(c0 == 255 || c1 == 255)) {          // some lane ran out of list space: exact redo by knn_fix_kernel
-        if (lane == 0) {
-            int pos = atomicAdd(p.ovf_count, 1);
-            if (pos < p.ovf_cap) p.ovf_list[pos] = make_int4(qcell, qwave * KM_QPW, ci, cj);
-        }
-        return;
-    }
-    unsigned long long keys[2][5];
-    float costs[2][5];
-    __shared__ uint16_t evl_all[4][KM_EVLIST][64];          // per wave: this lane's candidate indices, [slot][lane]
-    uint16_t (*evl)[64] = evl_all[threadIdx.x >> 6];
-    bool lane_ovf = false;
-#pragma unroll
-    for (int gq = 0; gq < 2; gq++) {
-        int qi = qwave * KM_QPW + gq * 32 + (lane & 31);
-        if (qi >= qnpts) qi = qnpts - 1;
-        const size_t qpix = (size_t)(qy0 + qi / qcw) * g.W + qx0 + qi % qcw;
-        float q[DFLOW_DESC];
-        {
-            const float4 *s = reinterpret_cast<const float4 *>(p.d1 + qpix * DFLOW_DESC);
-#pragma unroll
-            for (int k = 0; k < DFLOW_DESC / 4; k++) { float4 v = s[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
-        }
-#pragma unroll
-        for (int i = 0; i < 5; i++) { keys[gq][i] = 0x7F800000FFFFFFFFull; costs[gq][i] = 0.0f; }   // (+inf, no index)
-        // ---- expand this lane's (tile, mask) entries into a list of candidate indices (increasing), in LDS
-        const int n = gq == 0 ? c0 : c1;
-        const uint32_t *ev = p.ev + (size_t)lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + lane;
-        uint32_t ent[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) ent[e] = e < n ? ev[e * 64] : 0u;     // the first 8 entries are fetched together
-        int nev = 0;
-        auto expand = [&](uint32_t entry) {
-            const int tile = (int)(entry >> 16);
-            uint32_t mask = entry & 0xFFFFu;
-            while (mask) {
-                const int r = __ffs(mask) - 1;
-                mask &= mask - 1;
-                // accumulator register r of this lane = tile row 4 half + (r & 3) + 8 (r >> 2) = candidate row * ntiles + tile
-                if (nev < KM_EVLIST) evl[nev][lane] = (uint16_t)((4 * half + (r & 3) + 8 * (r >> 2)) * ntiles + tile);
-                nev++;
-            }
-        };
-#pragma unroll
-        for (int e = 0; e < 8; e++) expand(ent[e]);
-        for (int e = 8; e < n; e++) expand(ev[e * 64]);
-        lane_ovf |= nev > KM_EVLIST;
-        nev = min(nev, KM_EVLIST);
-        // The two half-lanes of a query (lane, lane ^ 32) hold the same descriptor and screened different tile rows: their
-        // lists are pooled (this half's entries first for half 0, the partner's first for half 1 -- any split works, the
-        // top-5 are merged below) and dealt out alternately, so both lanes evaluate half of the query's events.
-        const int nmine = nev, nother = __shfl_xor(nev, 32);
-        const int n0 = half == 0 ? nmine : nother, ntot = nmine + nother;      // n0 = entries of the half-0 lane
-        const int l0 = lane & 31;
-        // ---- canonical distance (sequential fmaf chain) and L1 cost (numpy pairwise order) of every listed candidate
-        for (int e = half; e < ntot; e += 2) {
-            const int idx = e < n0 ? evl[e][l0] : evl[e - n0][l0 + 32];
-            const float4 *c4 = reinterpret_cast<const float4 *>(p.d2 + ((size_t)(cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * DFLOW_DESC);
-            // The partial sums of the chain never decrease, so it stops once it exceeds the lane's current 5th best:
-            // such a candidate cannot enter the top 5 (it is then not inserted).  All 17 float4 of the row are fetched at once:
-            // the kernel is bound by L2 latency, not bandwidth.
-            const float worst = __uint_as_float((unsigned)(keys[gq][4] >> 32));
-            float acc = 0.0f, rs[8], tail[4];
-            bool dead = false;
-#pragma unroll
-            for (int seg = 0; seg < 1; seg++) {
-                const int ka = 0, kb = 17;
-                if (!dead) {
-#pragma unroll
-                    for (int k = ka; k < kb; k++) {
-                        const float4 v = c4[k];
-                        const float e0 = q[4 * k] - v.x, e1 = q[4 * k + 1] - v.y, e2 = q[4 * k + 2] - v.z, e3 = q[4 * k + 3] - v.w;
-                        acc = __fmaf_rn(e0, e0, acc); acc = __fmaf_rn(e1, e1, acc);
-                        acc = __fmaf_rn(e2, e2, acc); acc = __fmaf_rn(e3, e3, acc);
-                        const int j = (4 * k) & 7;
-                        if (k < 2) { rs[j] = fabsf(e0); rs[j + 1] = fabsf(e1); rs[j + 2] = fabsf(e2); rs[j + 3] = fabsf(e3); }
-                        else if (k < 16) { rs[j] = rs[j] + fabsf(e0); rs[j + 1] = rs[j + 1] + fabsf(e1); rs[j + 2] = rs[j + 2] + fabsf(e2); rs[j + 3] = rs[j + 3] + fabsf(e3); }
-                        else { tail[0] = fabsf(e0); tail[1] = fabsf(e1); tail[2] = fabsf(e2); tail[3] = fabsf(e3); }
-                    }
-                    dead = acc > worst;
-                }
-            }
-            if (dead) continue;
-            float l1 = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
-            l1 = l1 + tail[0]; l1 = l1 + tail[1]; l1 = l1 + tail[2]; l1 = l1 + tail[3];
-            key_insert(keys[gq], costs[gq], ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)idx, l1);
-        }
-        // the other half-lane screened the other 16 rows of every tile: merge
-        unsigned long long ok[5]; float oc[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) { ok[i] = __shfl_xor(keys[gq][i], 32); oc[i] = __shfl_xor(costs[gq][i], 32); }
-#pragma unroll
-        for (int i = 0; i < 5; i++) key_insert(keys[gq], costs[gq], ok[i], oc[i]);
-    }
-    if (__ballot(lane_ovf)) {                        // more candidates than list slots: exact redo by knn_fix_kernel
-        if (lane == 0) {
-            int pos = atomicAdd(p.ovf_count, 1);
-            if (pos < p.ovf_cap) p.ovf_list[pos] = make_int4(qcell, qwave * KM_QPW, ci, cj);
-        }
-        return;
-    }
-    // ---- emit (daisy i flann.py:174-180): lane l < 32 writes group 0 / column l, lane l >= 32 group 1 / column l-32
-    const int qi = qwave * KM_QPW + lane;
-    if (qi < qnpts) {
-        const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
-        const size_t pix = (size_t)qy * g.W + qx;
-        const int slot_base = 5 * wslot;
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const int idx = (int)((half == 0 ? keys[0][j] : keys[1][j]) & 0xFFFFFFFFu);
-            const float s = half == 0 ? costs[0][j] : costs[1][j];
-            const int ty = cy0 + idx / ccw, tx = cx0 + idx % ccw;
-            p.proposals[pix * a.LP + slot_base + j] = pack_flow(ty - qy, tx - qx);
-            p.lcosts[pix * a.LP + slot_base + j] = s < a.tphi ? s : a.tphi;
-        }
-    }
-}
-
-#ifndef KM_RESOLVE_V1
 // ------------------------------------------------------------------------------------------------ resolve, staged rows
-// knn_resolve_kernel (above, kept for A/B runs: -DKM_RESOLVE_V1) is bound by the L1's access rate: every lane fetches its
-// query row and each candidate row with 17 dwordx4 loads = 17 cache accesses per row (TCP_TOTAL_CACHE_ACCESSES = 1.1e9 per
-// launch, 0.94 per CU and cycle; 40 % of them for the query rows, which it fetches once per candidate cell).  Here
+// Round 1's kernel (one wave per (candidate cell, 64 queries) event list, every lane fetching its own rows with 17 dwordx4
+// loads) was bound by the L1's access rate: 17 cache accesses per row, TCP_TOTAL_CACHE_ACCESSES = 1.1e9 per launch = 0.94
+// per CU and cycle, 40 % of them for the query rows, which it fetched once per candidate cell.  Here
 //  * a wave keeps its 64 queries (lane = query: both half-lane lists of the query are pooled) over the window cells of
 //    one window column, so a query row is fetched once per 5 candidate cells;
 //  * the 64 rows of a round are fetched by the whole wave: one global_load_lds_dwordx4 covers 4 rows x 16 pieces of
@@ -614,8 +468,9 @@ __global__ void __launch_bounds__(256, 2) knn_resolve_kernel(KmGeom a, KmResolve
 //    (bytes 256..271) is fetched by its own lane.
 // One wave per block.  The arithmetic per (query, candidate) pair is that of knn_resolve_kernel and the top 5 are ordered
 // by the same (distance, index) keys, so the results are identical.
-#define KM_EVLIST2 32            // candidates per query and candidate cell listed in LDS (more: exact redo by knn_fix_kernel)
-__global__ void __launch_bounds__(64, 2) knn_resolve2_kernel(KmGeom a, KmResolve p)
+#define KM_EVLIST2 30            // candidates per query and candidate cell listed in LDS (more: exact redo by knn_fix_kernel);
+                                 // 30: stage + lists + offsets = 20 KB per wave = 8 waves per CU
+__global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve p)
 {
     const Geom g = a.g;
     const int lane = threadIdx.x, gq = lane >> 5, col = lane & 31;
@@ -685,18 +540,30 @@ __global__ void __launch_bounds__(64, 2) knn_resolve2_kernel(KmGeom a, KmResolve
     }
     const __attribute__((address_space(1))) char *d2g = (const __attribute__((address_space(1))) char *)p.d2;
 
+    // counts and first entries of the query's two event lists (half-lane 0: tile rows 0..3, 8..11, ...; half-lane 1: rows
+    // 4..7, 12..15, ...) of a candidate cell; fetched one cell ahead
+    const int nrows = cjmax - cjmin + 1;
+    int nA_n, nB_n; uint32_t entA_n[4], entB_n[4];
+    auto prefetch = [&](int cj) {
+        const size_t lid = list_id(a, qcell, qwave, (ci - cimin) * nrows + (cj - cjmin));
+        nA_n = p.ev_cnt[lid * 128 + gq * 64 + col]; nB_n = p.ev_cnt[lid * 128 + gq * 64 + col + 32];
+        const uint32_t *ev = p.ev + lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + col;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { entA_n[e] = ev[e * 64]; entB_n[e] = ev[e * 64 + 32]; }     // entries past the count are ignored below
+    };
+    prefetch(cjmin);
     for (int cj = cjmin; cj <= cjmax; cj++) {
-        const int wslot = (ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin);   // reference order: ci outer, cj inner (Q2)
+        const int wslot = (ci - cimin) * nrows + (cj - cjmin);   // reference order: ci outer, cj inner (Q2)
         const size_t lid = list_id(a, qcell, qwave, wslot);
         const int cy0 = g.y0(cj);
         const int ntiles = (ccw * (g.y1(cj) - cy0) + KM_CHUNK - 1) / KM_CHUNK * (KM_CHUNK / 32);   // as in the screen kernel
-        // the query's events: list of half-lane 0 (tile rows 0..3, 8..11, ...) and of half-lane 1 (rows 4..7, 12..15, ...)
-        const int nA = p.ev_cnt[(size_t)lid * 128 + gq * 64 + col], nB = p.ev_cnt[(size_t)lid * 128 + gq * 64 + col + 32];
+        const int nA = nA_n, nB = nB_n;
         bool ovf = nA == 255 || nB == 255;
         const uint32_t *evA = p.ev + (size_t)lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + col;
         uint32_t entA[4], entB[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { entA[e] = e < nA && !ovf ? evA[e * 64] : 0u; entB[e] = e < nB && !ovf ? evA[e * 64 + 32] : 0u; }   // the first entries are fetched together
+        for (int e = 0; e < 4; e++) { entA[e] = e < nA && !ovf ? entA_n[e] : 0u; entB[e] = e < nB && !ovf ? entB_n[e] : 0u; }
+        if (cj < cjmax) prefetch(cj + 1);
         int nev = 0;
         auto expand = [&](uint32_t entry, int h) {
             const int tile = (int)(entry >> 16);
@@ -784,7 +651,6 @@ __global__ void __launch_bounds__(64, 2) knn_resolve2_kernel(KmGeom a, KmResolve
         }
     }
 }
-#endif
 
 // ------------------------------------------------------------------------------------------------ finalize
 // nprop = 5 x window cells (daisy i flann.py:189), WTA label = first minimum of the costs with strict '<'
@@ -892,11 +758,7 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     KmResolve rs;
     rs.d1 = d1; rs.d2 = d2; rs.ev = ev; rs.ev_cnt = ev_cnt; rs.proposals = proposals; rs.lcosts = lcosts;
     rs.ovf_count = ctr; rs.ovf_list = ovf; rs.ovf_cap = KM_OVF_CAP;
-#ifdef KM_RESOLVE_V1
-    hipLaunchKernelGGL(knn_resolve_kernel, dim3((unsigned)(g.ncx * g.ncy * win * win * ((a.qwaves + 3) / 4))), dim3(256), 0, s, a, rs);
-#else
-    hipLaunchKernelGGL(knn_resolve2_kernel, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
-#endif
+    hipLaunchKernelGGL(knn_resolve_kernel, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
     rc = dflow_check_launch("knn_resolve_kernel");
     if (rc) return rc;
     rc = launch_knn_fix(p, d1, d2, proposals, lcosts, ctr, ovf, KM_OVF_CAP, ctr + 1, s);
