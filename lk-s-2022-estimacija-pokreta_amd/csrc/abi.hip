@@ -66,7 +66,9 @@ size_t dflow_workspace_bytes(const dflow_params *p)
 {
     if (dflow_check_params(p) != DFLOW_OK) return 0;
     size_t a = daisy_ws_bytes(p), b = bcd_ws_bytes(p), c = knn_mfma_supported(p) ? knn_mfma_ws_bytes(p) : 0;
+    size_t d = neighbour_ws_bytes(p);
     size_t m = a > b ? a : b;
+    if (d > m) m = d;
     return (m > c ? m : c) + 256;
 }
 

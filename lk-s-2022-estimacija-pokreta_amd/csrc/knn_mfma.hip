@@ -32,6 +32,7 @@
 // A workgroup is 8 waves x 64 queries (2 column groups) of one image-1 cell; candidates stream through LDS in
 // chunks of 96 rows (176-byte pitch: conflict-free ds_read_b128), double buffered by global_load_lds DMA.
 #include "dflow_common.h"
+#include "row_stage.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -468,7 +469,7 @@ __device__ static inline void key_insert(unsigned long long (&k)[5], float (&c)[
 //    (bytes 256..271) is fetched by its own lane.
 // One wave per block.  The arithmetic per (query, candidate) pair is that of knn_resolve_kernel and the top 5 are ordered
 // by the same (distance, index) keys, so the results are identical.
-#define KM_EVLIST2 30            // candidates per query and candidate cell listed in LDS (more: exact redo by knn_fix_kernel);
+#define KM_EVLIST2 30            // candidates per query and candidate cell listed in LDS at a time (more: further passes);
                                  // 30: stage + lists + offsets = 20 KB per wave = 8 waves per CU
 __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve p)
 {
@@ -486,44 +487,11 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
     const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
     const int cx0 = g.x0(ci), ccw = g.x1(ci) - cx0;
 
-    __shared__ __attribute__((aligned(1024))) char stage[64 * 256];   // LDS row r: pieces 0..15 of lane r's row, swizzled
+    __shared__ __attribute__((aligned(1024))) char stage[ROW_STAGE_BYTES];   // row_stage.h
     __shared__ uint16_t evl[KM_EVLIST2][64];                          // this query's candidate indices, [slot][lane]
     __shared__ __attribute__((aligned(16))) uint32_t s_cand[64];      // row offsets (16-byte units) of the round, [lane & 3][lane >> 2]
-    const int sub = lane >> 4;
-    // piece fetched by this lane in instruction k (LDS row 4k + sub, column lane & 15): (lane & 15) ^ ((4k & 15) | sub)
-    const uint32_t pz0 = (uint32_t)((lane & 15) ^ sub);
-    const uint32_t rd0 = (uint32_t)(lane * 256 + ((lane & 15) << 4));   // own row: the column of piece j is at rd0 ^ (j << 4)
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v tail_next = {0.f, 0.f, 0.f, 0.f};
-
-    // fetch of 64 rows (lane's row = 16-byte offset off16 from `base`; inactive lanes fetch nothing)
-    auto issue = [&](const __attribute__((address_space(1))) char *base, uint32_t off16, bool act) {
-        s_cand[(lane & 3) * 16 + (lane >> 2)] = act ? off16 : 0xFFFFFFFFu;
-        __syncthreads();
-        const uint4 *sc = reinterpret_cast<const uint4 *>(&s_cand[sub * 16]);
-        uint32_t cr[16];
-#pragma unroll
-        for (int k4 = 0; k4 < 4; k4++) { const uint4 v = sc[k4]; cr[4 * k4] = v.x; cr[4 * k4 + 1] = v.y; cr[4 * k4 + 2] = v.z; cr[4 * k4 + 3] = v.w; }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (cr[k] != 0xFFFFFFFFu) {
-                const uint32_t piece = pz0 ^ (uint32_t)((4 * k) & 15);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + ((unsigned long long)(cr[k] + piece) << 4)),
-                                                 (__attribute__((address_space(3))) void *)(stage + k * 1024), 16, 0, 0);
-            }
-        }
-        if (act) tail_next = *reinterpret_cast<const __attribute__((address_space(1))) f4v *>(base + ((unsigned long long)(off16 + 16u) << 4));
-    };
-    auto fetch_rows = [&](float4 (&cv)[17]) {            // the staged rows -> registers (the stage buffer is free afterwards)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; j++) cv[j] = *reinterpret_cast<const float4 *>(stage + (rd0 ^ (uint32_t)(j << 4)));
-        cv[16] = make_float4(tail_next.x, tail_next.y, tail_next.z, tail_next.w);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-
+    RowStage rows;
+    rows.init(stage, s_cand, lane);
     // ---- the queries of this wave
     float q[DFLOW_DESC];
     int qi = qwave * KM_QPW + lane;
@@ -532,13 +500,13 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
     const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
     const size_t qpix = (size_t)qy * g.W + qx;
     {
-        issue((const __attribute__((address_space(1))) char *)p.d1, (uint32_t)qpix * 17u, true);
+        rows.issue((rs_gptr)p.d1, (uint32_t)qpix * 17u, true);
         float4 qv[17];
-        fetch_rows(qv);
+        rows.fetch(qv);
 #pragma unroll
         for (int k = 0; k < 17; k++) { q[4 * k] = qv[k].x; q[4 * k + 1] = qv[k].y; q[4 * k + 2] = qv[k].z; q[4 * k + 3] = qv[k].w; }
     }
-    const __attribute__((address_space(1))) char *d2g = (const __attribute__((address_space(1))) char *)p.d2;
+    const rs_gptr d2g = (rs_gptr)p.d2;
 
     // counts and first entries of the query's two event lists (half-lane 0: tile rows 0..3, 8..11, ...; half-lane 1: rows
     // 4..7, 12..15, ...) of a candidate cell; fetched one cell ahead
@@ -564,28 +532,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
 #pragma unroll
         for (int e = 0; e < 4; e++) { entA[e] = e < nA && !ovf ? entA_n[e] : 0u; entB[e] = e < nB && !ovf ? entB_n[e] : 0u; }
         if (cj < cjmax) prefetch(cj + 1);
-        int nev = 0;
-        auto expand = [&](uint32_t entry, int h) {
-            const int tile = (int)(entry >> 16);
-            uint32_t mask = entry & 0xFFFFu;
-            while (mask) {
-                const int r = __ffs(mask) - 1;
-                mask &= mask - 1;
-                // accumulator register r of half-lane h = tile row 4 h + (r & 3) + 8 (r >> 2) = candidate row * ntiles + tile
-                if (nev < KM_EVLIST2) evl[nev][lane] = (uint16_t)((4 * h + (r & 3) + 8 * (r >> 2)) * ntiles + tile);
-                nev++;
-            }
-        };
-        if (!ovf) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) expand(entA[e], 0);
-            for (int e = 4; e < nA; e++) expand(evA[e * 64], 0);
-#pragma unroll
-            for (int e = 0; e < 4; e++) expand(entB[e], 1);
-            for (int e = 4; e < nB; e++) expand(evA[e * 64 + 32], 1);
-        }
-        ovf |= nev > KM_EVLIST2;
-        if (__ballot(ovf)) {                             // out of list space somewhere: exact redo of this list by knn_fix_kernel
+        if (__ballot(ovf)) {                             // an event list ran out of entries in the screen: exact redo by knn_fix_kernel
             if (lane == 0) {
                 int pos = atomicAdd(p.ovf_count, 1);
                 if (pos < p.ovf_cap) p.ovf_list[pos] = make_int4(qcell, qwave * KM_QPW, ci, cj);
@@ -596,11 +543,33 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
         float costs[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) { keys[i] = 0x7F800000FFFFFFFFull; costs[i] = 0.0f; }   // (+inf, no index)
-
+        // The LDS list holds KM_EVLIST2 candidates per query; a query with more events (flat or repetitive image regions)
+        // takes further passes over its entries: `done` events have been evaluated, the next KM_EVLIST2 are listed.
+        int done = 0, total;
+        do {
+        int nev = 0, seen = 0;
+        auto expand = [&](uint32_t entry, int h) {
+            const int tile = (int)(entry >> 16);
+            uint32_t mask = entry & 0xFFFFu;
+            while (mask) {
+                const int r = __ffs(mask) - 1;
+                mask &= mask - 1;
+                // accumulator register r of half-lane h = tile row 4 h + (r & 3) + 8 (r >> 2) = candidate row * ntiles + tile
+                if (seen >= done && nev < KM_EVLIST2) { evl[nev][lane] = (uint16_t)((4 * h + (r & 3) + 8 * (r >> 2)) * ntiles + tile); nev++; }
+                seen++;
+            }
+        };
+#pragma unroll
+        for (int e = 0; e < 4; e++) expand(entA[e], 0);
+        for (int e = 4; e < nA; e++) expand(evA[e * 64], 0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) expand(entB[e], 1);
+        for (int e = 4; e < nB; e++) expand(evA[e * 64 + 32], 1);
+        total = seen;
         auto issue_cand = [&](int e) -> int {
             const bool act = e < nev;
             const int idx = act ? evl[e][lane] : 0;
-            issue(d2g, (uint32_t)((cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * 17u, act);
+            rows.issue(d2g, (uint32_t)((cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * 17u, act);
             return idx;
         };
         if (__ballot(nev > 0)) {
@@ -608,7 +577,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
             int idx_next = issue_cand(0);
             while (true) {
                 float4 cv[17];
-                fetch_rows(cv);
+                rows.fetch(cv);
                 const bool act = e < nev;
                 const int idx = idx_next;
                 e++;
@@ -636,6 +605,8 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
                 if (!more) break;
             }
         }
+        done += nev;
+        } while (__ballot(done < total));
         // ---- emit (daisy i flann.py:174-180)
         if (qvalid) {
             const size_t pix = (size_t)qy * g.W + qx;
