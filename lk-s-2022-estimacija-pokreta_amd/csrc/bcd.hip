@@ -57,6 +57,8 @@ struct BcdPlanes {
     uint32_t *masks;                 // [pix][2][LP][5]      160-bit rows (rows with more than 15 members only)
 };
 
+template <int V> struct BcdC { static constexpr int value = V; };
+
 // ------------------------------------------------------------------------------------------------ lists
 // grid: one wave per (pixel, dir); dir 0 = the pixel's column chain, dir 1 = its row chain.
 __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, int tpsi, const uint32_t *__restrict__ proposals,
@@ -99,22 +101,27 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
     const uint32_t kbias = 0x80000000u - (uint32_t)tpsi;
     const uint32_t *__restrict__ colp = proposals + (size_t)ppix * LP;
     uint32_t m[3][BCD_MASK_WORDS];
+    // a pixel with at most 128 labels (44 % of the frame: fewer than 25 window cells) has no third lane group: its rows stay
+    // "not compatible" and are never used
+    auto build = [&](auto third) {
 #pragma unroll
-    for (int j = 0; j < BCD_MASK_WORDS; j++) {
-        m[0][j] = m[1][j] = m[2][j] = 0xFFFFFFFFu;
-        if (32 * j < pn) {
+        for (int j = 0; j < BCD_MASK_WORDS; j++) {
+            m[0][j] = m[1][j] = m[2][j] = 0xFFFFFFFFu;
+            if (32 * j < pn) {
 #pragma unroll
-            for (int cc = 31; cc >= 0; cc--) {
-                const uint32_t col = flow_bias(colp[32 * j + cc]);
-                m[0][j] = __builtin_amdgcn_alignbit(m[0][j], __builtin_amdgcn_sad_u16(col, fcv[0], kbias), 31);
-                m[1][j] = __builtin_amdgcn_alignbit(m[1][j], __builtin_amdgcn_sad_u16(col, fcv[1], kbias), 31);
-                m[2][j] = __builtin_amdgcn_alignbit(m[2][j], __builtin_amdgcn_sad_u16(col, fcv[2], kbias), 31);
+                for (int cc = 31; cc >= 0; cc--) {
+                    const uint32_t col = flow_bias(colp[32 * j + cc]);
+                    m[0][j] = __builtin_amdgcn_alignbit(m[0][j], __builtin_amdgcn_sad_u16(col, fcv[0], kbias), 31);
+                    m[1][j] = __builtin_amdgcn_alignbit(m[1][j], __builtin_amdgcn_sad_u16(col, fcv[1], kbias), 31);
+                    if (decltype(third)::value) m[2][j] = __builtin_amdgcn_alignbit(m[2][j], __builtin_amdgcn_sad_u16(col, fcv[2], kbias), 31);
+                }
+                const int nv = pn - 32 * j;                  // valid columns in this word (wave-uniform)
+                const uint32_t inval = nv >= 32 ? 0u : ~0u << nv;
+                m[0][j] |= inval; m[1][j] |= inval; m[2][j] |= inval;
             }
-            const int nv = pn - 32 * j;                      // valid columns in this word (wave-uniform)
-            const uint32_t inval = nv >= 32 ? 0u : ~0u << nv;
-            m[0][j] |= inval; m[1][j] |= inval; m[2][j] |= inval;
         }
-    }
+    };
+    if (tn > 128) build(BcdC<1>()); else build(BcdC<0>());
     const size_t rowbase = ((size_t)pix * 2 + dir) * (size_t)LP;
     const size_t grpbase = ((size_t)pix * 2 + dir) * (size_t)(BCD_GROUPS * 64);
 #pragma unroll
