@@ -189,7 +189,9 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
 }
 
 // ------------------------------------------------------------------------------------------------ chains
+#ifndef BCD_MAX_BATCH
 #define BCD_MAX_BATCH 8
+#endif
 struct BcdPass {
     const int32_t *nprop;
     int32_t *bestlabels;
