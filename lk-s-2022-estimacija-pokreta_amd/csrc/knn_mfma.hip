@@ -204,7 +204,10 @@ struct KmScreen {
 __device__ static inline void top5_insert_desc(float (&a)[5], float m)
 {
 #pragma unroll
-    for (int i = 0; i < 5; i++) { float hi = fmaxf(a[i], m); m = fminf(a[i], m); a[i] = hi; }
+    // a is sorted (descending): the new a[i] is the median of (old a[i-1], old a[i], m); one v_med3_f32 per slot instead
+    // of a max / min pair
+    for (int i = 4; i >= 1; i--) a[i] = __builtin_amdgcn_fmed3f(a[i - 1], a[i], m);
+    a[0] = fmaxf(a[0], m);
 }
 
 __device__ static inline float max16(const f32x16 &v)
