@@ -31,3 +31,11 @@ m = masks.copy()
 for i in range(16): pc += (m>>i)&1
 evs = (pc*valid).sum(2)   # per list, group, lane
 print('events/lane mean %.2f p99 %d max %d ; events per query (2 lanes) mean %.2f'%(evs.mean(), np.percentile(evs,99), evs.max(), (evs[:,:,:32]+evs[:,:,32:]).mean()))
+# resolve kernel (round 2): lane = query, rounds of a (wave, cell) = the largest event count among its 64 queries
+q = (evs[:, :, :32] + evs[:, :, 32:]).reshape(len(evs), 64)
+rounds = q.max(1)
+print('per query events mean %.2f; rounds per (wave, cell) mean %.2f p50 %d p90 %d p99 %d max %d; lane utilisation %.1f %%' % (
+    q.mean(), rounds.mean(), np.percentile(rounds, 50), np.percentile(rounds, 90), np.percentile(rounds, 99), rounds.max(), 100 * q.mean() / rounds.mean()))
+h = np.bincount(np.minimum(q.reshape(-1), 40))
+print('events per query histogram (0..40+):', h.tolist())
+# if every lane walked its 5 cells' candidates back to back (no per-cell synchronisation): rounds per wave = max over lanes of the sum
