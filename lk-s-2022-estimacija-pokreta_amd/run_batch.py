@@ -30,6 +30,7 @@ def main(argv=None):
     ap.add_argument("--group", type=int, default=4, help="passes of a rank whose BCD sweeps share their launches")
     ap.add_argument("--cell", default=None, help="cell size HxW (default: the geometry's usual cells)")
     ap.add_argument("--fp16-descriptors", action="store_true", help="DAISY values rounded to binary16 (BASELINE configs[4])")
+    ap.add_argument("--time", action="store_true", help="run the passes twice and report the wall time of the second run")
     a = ap.parse_args(argv)
     import torch
     import torch.distributed as dist
@@ -59,22 +60,51 @@ def main(argv=None):
     ch, cw = (int(v) for v in a.cell.lower().split("x")) if a.cell else (None, None)
     dfs = [pipeline.DiscreteFlow(H, W, ch, cw, device=dev, seed=rank, flags=flags) for _ in range(group)]
 
+    front = [torch.cuda.Stream(device=dev) for _ in range(min(3, group))]     # front ends of a group's passes side by side
+
     def compute_many(descs):
         flows = []
+        main = torch.cuda.current_stream(dev)
         for g0 in range(0, len(descs), group):
             part = descs[g0:g0 + group]
-            for df, (pair, backward) in zip(dfs, part):
+            start = torch.cuda.Event()
+            start.record(main)                                   # the previous group's read-out is done
+            done = []
+            for j, (df, (pair, backward)) in enumerate(zip(dfs, part)):
                 img1, img2 = images[pair]
                 if backward:
                     img1, img2 = img2, img1
-                df.load_pair(img1, img2)
-                df.generisi()
-                df.nasumicni()
+                st = front[j % len(front)]
+                with torch.cuda.stream(st):
+                    st.wait_event(start)
+                    df.load_pair(img1, img2)
+                    df.generisi()
+                    df.nasumicni()
+                    df.pakovanje()
+                    e = torch.cuda.Event()
+                    e.record(st)
+                    done.append(e)
+            for e in done:
+                main.wait_event(e)
             pipeline.ceoBCD_batch(dfs[:len(part)], a.bcd_times)
             flows += [df.vratiKonacniFlow().clone() for df in dfs[:len(part)]]
         return flows
 
     flows = sharding.run_passes(passes, None, world, rank, dfs[0].flow, compute_many=compute_many)
+    if a.time:
+        import time
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        flows = sharding.run_passes(passes, None, world, rank, dfs[0].flow, compute_many=compute_many)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print("%d passes (%d pairs, forward + backward) of %dx%d, bcd_times=%d on %d GPU(s): %.1f ms = %.2f ms per pass = %.1f Mpix/s"
+                  % (len(passes), a.pairs, W, H, a.bcd_times, world, dt * 1e3, dt * 1e3 / len(passes), len(passes) * H * W / dt / 1e6))
     if rank == 0:
         os.makedirs(a.out, exist_ok=True)
         for pair in range(a.pairs):
