@@ -458,7 +458,8 @@ def test_large_frame_invariants(torch_, oracle, synth):
 
 @pytest.mark.parametrize("over", [dict(tpsi=5, tphi=1.5, lamda=0.1, ngauss=10, sigma=4.0),
                                   dict(tpsi=1, tphi=0.75, lamda=1.0, ngauss=25, sigma=8.0, maxnprop=160),
-                                  dict(tpsi=8, tphi=2.5, lamda=0.05, ngauss=0, window=1)])
+                                  dict(tpsi=8, tphi=2.5, lamda=0.05, ngauss=0, window=1),
+                                  dict(tpsi=8, tphi=2.5, lamda=0.05, ngauss=25, window=0, maxnprop=40)])
 def test_non_default_constants_match_oracle(torch_, oracle, synth, over):
     """The module globals of the reference (tpsi, tphi, lamda, ngauss, sigma, maxnprop, window) are parameters of the ABI:
     other values than the reference's go through the same kernels and must agree with the oracle stage by stage."""
