@@ -39,3 +39,17 @@ print('per query events mean %.2f; rounds per (wave, cell) mean %.2f p50 %d p90 
 h = np.bincount(np.minimum(q.reshape(-1), 40))
 print('events per query histogram (0..40+):', h.tolist())
 # if every lane walked its 5 cells' candidates back to back (no per-cell synchronisation): rounds per wave = max over lanes of the sum
+# what pooling the tails (events beyond the 5th) of the cells of a window column would save: interior query cells only
+allq = np.zeros((nl, 64), np.int32); allq[act] = q
+lists = allq.reshape(ncx * ncy, qwaves, 25, 64)
+cells = np.arange(ncx * ncy); ci, cj = cells % ncx, cells // ncx
+inner = (ci >= 2) & (ci < ncx - 2) & (cj >= 2) & (cj < ncy - 2)
+L = lists[inner][:, :qwaves - 1]                       # full waves only; [cell, qwave, slot = col*5 + row, query]
+L = L.reshape(L.shape[0], L.shape[1], 5, 5, 64)        # [cell, qwave, col, row, query]
+L = L[L.reshape(L.shape[0], L.shape[1], -1).max(-1) > 0]      # waves that hold queries: [wave, col, row, query]
+t = np.maximum(L - 5, 0)
+cur = L.max(-1).sum(-1)                                # rounds of a (wave, column) today
+pair = 25 + (t[..., 0, :] + t[..., 1, :]).max(-1) + (t[..., 2, :] + t[..., 3, :]).max(-1) + t[..., 4, :].max(-1)
+pool = 25 + t.sum(-2).max(-1)
+print('rounds per (wave, window column): today %.2f, tails pooled in pairs of cells %.2f, tails of all 5 cells pooled %.2f, minimum %.2f'
+      % (cur.mean(), pair.mean(), pool.mean(), L.sum(-2).mean()))
