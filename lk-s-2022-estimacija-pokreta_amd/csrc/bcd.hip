@@ -473,34 +473,32 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
             perm.v = __longlong_as_double((long long)pmn); perm.k = pix_;
             small = __dadd_rn(__dadd_rn(__dmul_rn(lamda, (double)lc), (double)s1), (double)s2);
         }
-        double bestv = 1e300; uint32_t besta = 0x7fffffffu;
+        // first minimum of a block as a tree (depth 3 instead of a chain of 5 dependent compare / select steps): the members
+        // are in increasing k, so "the right operand wins only if strictly smaller" keeps the first minimum at every node
+        auto node = [](double &va, uint32_t &ka, const double vb, const uint32_t kb) {
+            const bool t = vb < va;
+            va = __builtin_fmin(va, vb); ka = t ? kb : ka;
+        };
+        auto block_min = [&](double (&d)[BCD_BLK], uint32_t (&k)[BCD_BLK], const uint32_t y, double &v, uint32_t &kk) {
 #pragma unroll
-        for (int j = 0; j < BCD_BLK; j++) {
-            const double c = __dadd_rn(dd[j], (double)((ay >> (8 + 4 * j)) & 7u));
-            const bool t = c < bestv;               // +inf + psi = +inf never wins
-            bestv = __builtin_fmin(bestv, c); besta = t ? ad[j] : besta;
-        }
+            for (int j = 0; j < BCD_BLK; j++) d[j] = __dadd_rn(d[j], (double)((y >> (8 + 4 * j)) & 7u));    // +inf + psi = +inf
+            node(d[0], k[0], d[1], k[1]); node(d[2], k[2], d[3], k[3]);
+            node(d[0], k[0], d[2], k[2]); node(d[0], k[0], d[4], k[4]);
+            v = d[0]; kk = k[0];
+        };
+        double bestv; uint32_t besta;
+        block_min(dd, ad, ay, bestv, besta);
         // second block: some label of the wave has more than 5 members (almost always true for a full wave)
         if ((ballot64((ay >> 28) > BCD_BLK) & actmask) != 0ull) {
             uint32_t a2[BCD_BLK]; double d2[BCD_BLK];
 #pragma unroll
             for (int j = 0; j < BCD_BLK; j++) { a2[j] = ((j < 4 ? bx >> (8 * j) : by) & 0xFFu) << 3; d2[j] = *reinterpret_cast<const double *>(prev + a2[j]); }
-#pragma unroll
-            for (int j = 0; j < BCD_BLK; j++) {
-                const double c = __dadd_rn(d2[j], (double)((by >> (8 + 4 * j)) & 7u));
-                const bool t = c < bestv;
-                bestv = __builtin_fmin(bestv, c); besta = t ? a2[j] : besta;
-            }
+            { double vb; uint32_t kb; block_min(d2, a2, by, vb, kb); node(bestv, besta, vb, kb); }
             // third block (a quarter of the waves), rows beyond 15 members (2 % of the workgroup steps)
             if (__builtin_expect((ballot64((ay >> 28) > 2 * BCD_BLK) & actmask) != 0ull, 0)) {
 #pragma unroll
                 for (int j = 0; j < BCD_BLK; j++) { a2[j] = ((j < 4 ? cx >> (8 * j) : cy) & 0xFFu) << 3; d2[j] = *reinterpret_cast<const double *>(prev + a2[j]); }
-#pragma unroll
-                for (int j = 0; j < BCD_BLK; j++) {
-                    const double c = __dadd_rn(d2[j], (double)((cy >> (8 + 4 * j)) & 7u));
-                    const bool t = c < bestv;
-                    bestv = __builtin_fmin(bestv, c); besta = t ? a2[j] : besta;
-                }
+                { double vc; uint32_t kc; block_min(d2, a2, cy, vc, kc); node(bestv, besta, vc, kc); }
                 const bool more = act && (ay & 0x800u) != 0u;
                 if (__builtin_expect(ballot64(more) != 0ull, 0)) {
                     // denser rows still: those lanes fetch their 160-bit row and walk what is left behind the 15th list
@@ -548,7 +546,7 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
         // back-pointer columns LP..191, equally unreferenced.
         unsigned long long key;
         {
-            const bool found = besta != 0x7fffffffu;
+            const bool found = bestv < 1e300;        // no compatible predecessor: every slot read the +inf tail
             const double mincost = found ? bestv : perm.v;
             const int pl_ = found ? (int)(besta >> 3) : perm.k;
             const double dpc = __dadd_rn(mincost, small);
