@@ -20,9 +20,9 @@
 //                      (dp = mincost + ((lamda*lcost + s1) + s2); first-index ties everywhere, Q9-Q11).  dp lives in LDS
 //                      (double buffered), the blocks are prefetched four (first block, label data) and two (second and
 //                      third block) steps ahead, back-pointers go to the workspace as uint8 and are walked chunk-wise from
-//                      LDS.  17 KB of LDS and <= 80 VGPRs: eight workgroups per CU, so a batch of four passes is resident
-//                      at once and the kernel runs in a throughput regime (HBM streams of the blocks) instead of waiting
-//                      on one chain step at a time.
+//                      LDS.  11 KB of static + the chain's dynamic LDS and 88 VGPRs (__launch_bounds__(192, 5)): six
+//                      workgroups per CU (the measured optimum), so with the chains of 8 passes in one
+//                      launch the kernel runs in a throughput regime instead of waiting on one chain step at a time.
 #include "dflow_common.h"
 
 #define BCD_THREADS 192
