@@ -484,6 +484,46 @@ def test_non_default_constants_match_oracle(torch_, oracle, synth, over):
         pkg("pipeline").DiscreteFlow(H, W, ch, cw, tpsi=9)
 
 
+def _random_geometries(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(n):
+        ch, cw = int(rng.integers(3, 20)), int(rng.integers(3, 24))
+        ncy, ncx = int(rng.integers(1, 8)), int(rng.integers(1, 9))
+        H, W = max(24, ch * ncy + int(rng.integers(0, ch))), max(24, cw * ncx + int(rng.integers(0, cw)))
+        window, ngauss = int(rng.integers(0, 3)), int(rng.choice([0, 7, 25]))
+        out.append((H, W, ch, cw, window, ngauss))
+    return out
+
+
+@pytest.mark.parametrize("geom", _random_geometries(10, 7))
+def test_random_geometries_match_oracle(torch_, oracle, synth, geom):
+    """Randomly drawn image sizes, cell sizes (down to 3x9 pixels, ragged last cells, single-row cell grids) and windows
+    (0..2): kNN proposals, neighbour proposals and one BCD sweep against the oracle, bit for bit (scratch/fuzz_geoms.py runs
+    more of them)."""
+    O = oracle
+    H, W, ch, cw, window, ngauss = geom
+    over = dict(window=window, ngauss=ngauss, maxnprop=5 * (2 * window + 1) ** 2 + ngauss)
+    df = pkg("pipeline").DiscreteFlow(H, W, ch, cw, seed=H + W, **over)
+    p = O.make_params(H, W, ch, cw, seed=H + W, **over)
+    img1, img2, _ = synth.make_pair(H, W, seed=100 + H, amp_x=0.08 * W, amp_y=0.08 * H)
+    df.load_pair(img1, img2)
+    d1, d2 = O.daisy(img1), O.daisy(img2)
+    df.generisi()
+    pr, lc, npr, bl = O.knn_proposals(p, d1, d2)
+    st = df.host_state()
+    for k, v in (("nprop", npr), ("proposals", pr), ("lcosts", lc), ("bestlabels", bl)):
+        assert np.array_equal(st[k], v), (geom, "knn", k)
+    df.nasumicni()
+    O.neighbour_proposals(p, d1, d2, pr, lc, npr, bl)
+    st = df.host_state()
+    for k, v in (("nprop", npr), ("proposals", pr), ("lcosts", lc)):
+        assert np.array_equal(st[k], v), (geom, "neighbour", k)
+    df.ceoBCD(1)
+    O.bcd_sweep(p, pr, lc, npr, bl)
+    assert np.array_equal(df.bestlabels.cpu().numpy(), bl), (geom, "sweep")
+
+
 def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
     """The two drop-in CLIs on a synthetic pair: file names, dtypes and contents as the reference writes them."""
     import runpy, sys, os
