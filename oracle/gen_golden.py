@@ -160,9 +160,11 @@ def run_reference_pass(p, img_first, img_second, idx, backward, bcd_times, workd
     return out
 
 
-def make_fixture(name, H, W, cellh, cellw, seed, bcd_times=3, idx=6):
+def make_fixture(name, H, W, cellh, cellw, seed, bcd_times=3, idx=6, unrelated=False):
     p = O.make_params(H, W, cellh, cellw, seed=seed)
     img1, img2, gt = synth.make_pair(H, W, seed=seed, amp_x=0.12 * W, amp_y=0.12 * H)
+    if unrelated:          # second image of a different scene: no proposal is good, the neighbour stage appends many more
+        img2 = synth.make_pair(H, W, seed=seed + 1, amp_x=0.12 * W, amp_y=0.12 * H)[0]
     store = dict(name=name, H=H, W=W, cellh=cellh, cellw=cellw, seed=np.uint64(seed), bcd_times=bcd_times,
                  img1=img1, img2=img2, gt=gt.astype(np.float32))
     fields = {}
@@ -250,6 +252,16 @@ def make_fixture(name, H, W, cellh, cellw, seed, bcd_times=3, idx=6):
     print("wrote", out, os.path.getsize(out), "bytes")
 
 
+FIXTURES = {
+    "a40x48_c5x6": dict(H=40, W=48, cellh=5, cellw=6, seed=11),
+    "b36x40_c9x8": dict(H=36, W=40, cellh=9, cellw=8, seed=23),
+    # odd x odd with exact tiling, like the reference's only native size 1241x375 (daisy i flann.py:34-35): the odd-index
+    # phase enumeration range((picw//2)*2-1,-1,-2) (python bcd.py:273,276) ends one short of the last column / row here
+    "c45x35_c9x7": dict(H=45, W=35, cellh=9, cellw=7, seed=37),
+    # two unrelated images, every cell inside the +-2 window: 125 kNN labels + up to 25 appended ones per pixel
+    "d45x35_c9x7_unrelated": dict(H=45, W=35, cellh=9, cellw=7, seed=41, unrelated=True),
+}
+
 if __name__ == "__main__":
-    make_fixture("a40x48_c5x6", 40, 48, 5, 6, seed=11)
-    make_fixture("b36x40_c9x8", 36, 40, 9, 8, seed=23)
+    for name in (sys.argv[1:] or FIXTURES):          # no arguments: regenerate all of them
+        make_fixture(name, **FIXTURES[name])

@@ -40,4 +40,4 @@ def golden():
     return load
 
 
-GOLDEN_NAMES = ("a40x48_c5x6", "b36x40_c9x8")
+GOLDEN_NAMES = ("a40x48_c5x6", "b36x40_c9x8", "c45x35_c9x7", "d45x35_c9x7_unrelated")
