@@ -4,22 +4,30 @@
 // bit for bit -- but the 1.7e10 descriptor pairs of a Sintel pass are screened by f16 MFMA instead of being
 // evaluated one by one:
 //
-//   prep      a fixed centre mu (mean descriptor of a pixel sample, knn_mean_kernel) is subtracted from both images --
-//             distances do not change, the products get smaller -- and both become rows of 80 f16: 68 values
-//             x~ = f16(64 (x - mu)), then for image 2 two f16 triples h-, h+ of h = 0.5*|64 (c - mu)|^2 (enlarged / reduced
-//             by the candidate's share of the error bound, see below), for image 1 the matching -1 / 0 selectors, zero
-//             padding.  With G^ = the MFMA's value of q~.c~ (exact products, f32 accumulation) and E = x~ - 64 (x - mu) the
-//             rounding errors actually made (their norms are computed here, nothing is assumed about f16 rounding),
-//                 |q.c - G^| <= |q~||E_c| + |E_q||c| + eta (|q~||c~| + h)  <=  S_c + S_q,
-//                 S_c = |E_c|^2/(2t) + (t/2)|c|^2 + eta (|c~|^2/2 + h),   S_q = (t/2)|q~|^2 + |E_q|^2/(2t) + (eta/2)|q~|^2
-//             (t = 2^-12.5; eta = 2^-12 bounds the f32 accumulation of the 74 products inside the matrix core, about 25
-//             times what IEEE summation would need), so tau = q.c - h = 0.5(|q|^2 - 64^2 d^2) lies within S_c + S_q of G^ - h.
-//   screen    (knn_screen_kernel) pass 1: w = G^ - h- with h- = h + S_c for every (query, candidate) of a (256-query block,
+//   basis     a fixed centre mu (mean descriptor of a pixel sample, knn_mean_kernel) and the principal axes V of a sample
+//             of image-2 descriptors (knn_pca.hip, float64).  x = 64 (d - mu), y = V^T x: distances do not change
+//             (V orthonormal to 1e-9, measured), the products get smaller, and the energy of y collects in its leading
+//             components: the screen multiplies the first KM_KD = 42 of them (y_P) and bounds the product of the dropped 26
+//             (y_D) by Cauchy-Schwarz, |y_D(q) . y_D(c)| <= n_q n_c with n >= |y_D|.
+//   prep      (knn_prep_kernel) both images become rows of KM_K = 48 f16: y~ = f16(y_P), then for image 2 n_c, two f16
+//             pieces of h = 0.5 |x_c|^2, the candidate's share S_c of the error bound and two 1.0; for image 1 n_q and the
+//             matching selectors.  With G^ = the MFMA's value of y~_q . y~_c (exact products, f32 accumulation) and
+//             E = y~ - y_P the rounding errors actually made (their norms are computed here in float64, nothing is assumed
+//             about f16 rounding),
+//                 |y_P(q) . y_P(c) - G^| <= |y~_q||E_c| + |E_q||y_P(c)| + eta (sum of |products|)  <=  S_c + S_q,
+//                 S_c = |E_c|^2/(2t) + (t/2)|y_P(c)|^2 + eta (|y~_c|^2/2 + n_c^2/2 + h) + 2e-6 h,
+//                 S_q = (t/2)|y~_q|^2 + |E_q|^2/(2t) + (eta/2)(|y~_q|^2 + n_q^2)
+//             (t = 2^-12.5; eta = 2^-12 bounds the f32 accumulation of the 48 products inside the matrix core, about 40
+//             times what IEEE summation would need; 2e-6 h covers the two-piece representation of h, |V^T V - I| and the
+//             float32 rounding of d - mu), so tau = y_q . y_c - 0.5 |y_c|^2 = 0.5 (|y_q|^2 - |y_q - y_c|^2) lies within
+//             n_q n_c + S_c + S_q of G^ - h.
+//   screen    (knn_screen_kernel) pass 1: w = G^ - n_q n_c - h - S_c for every (query, candidate) of a (64-query wave,
 //             candidate cell); w - S_q <= tau.  Every lane keeps the 5 largest maxima of its 16-value tile columns -> a5,
-//             and a5 - S_q is a lower bound of the 5th largest tau of the query.  pass 2: v = G^ - h+ with h+ = h - S_c;
+//             and a5 - S_q is a lower bound of the 5th largest tau of the query.  pass 2: v = G^ + n_q n_c - h + S_c;
 //             v + S_q >= tau.  Only candidates with v >= a5 - 2 S_q - s (s: rounding of the canonical float32 distance)
 //             can be among the exact 5 NN: these "events" (a 16-bit row mask per lane and tile) go to per-lane lists in
-//             the workspace.
+//             the workspace.  Events per (query, cell) on the bench frame: 5.7 (5 is the minimum; all 68 dimensions in
+//             the product, 5 MFMAs per tile instead of 3, gave 5.5).
 //   resolve   (knn_resolve_kernel) one wave per (64 queries, window column): canonical float32 distance (sequential
 //             fmaf chain) and truncated L1 cost (numpy order) of every event, exact (distance, index) top-5 in
 //             registers, proposals [dy,dx] and costs into the cell's 5 slots (Q1-Q3).  The rows are fetched by the
@@ -29,9 +37,10 @@
 //
 // MFMA layout (v_mfma_f32_32x32x16_f16): A = candidates (rows), B = queries (columns): lane l holds
 // A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31]; D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5).
-// A workgroup is 8 waves x 64 queries (2 column groups) of one image-1 cell; candidates stream through LDS in
-// chunks of 96 rows (176-byte pitch: conflict-free ds_read_b128), double buffered by global_load_lds DMA.
+// A workgroup is 8 waves x 64 queries (2 column groups); candidates stream through LDS in chunks of 96 rows (112-byte
+// pitch: conflict-free ds_read_b128) through a ring of 4 buffers filled by global_load_lds DMA.
 #include "dflow_common.h"
+#include "knn_pca.h"
 #include "row_stage.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -39,20 +48,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int V> struct KmC { static constexpr int value = V; };
 
 #define KM_ALPHA 64.0f
-#define KM_K 80                 // f16 per prepared row (160 bytes)
+#define KM_K 48                 // f16 per prepared row (96 bytes)
+#define KM_KSTEPS (KM_K / 16)   // MFMAs per 32x32 tile
+#define KM_KD 42                // leading principal components in the matrix product
+#define KM_SLOT_N 42            // n = bound of the norm of the dropped components
+#define KM_SLOT_H 43            // 43, 44: two f16 pieces of h (candidates) / -1, -1 (queries)
+#define KM_SLOT_S 45            // S_c (candidates) / -1 in pass 1, +1 in pass 2 (queries)
+#define KM_SLOT_ONE 46          // 46, 47: 1.0 (candidates) / minus the two pieces of the threshold in pass 2 (queries)
 #define KM_WAVES 8
 #define KM_THREADS (64 * KM_WAVES)
 #define KM_QPW 64               // queries per wave: 2 column groups of 32
 #define KM_QPB (KM_WAVES * KM_QPW)
 #define KM_CHUNK 96             // candidates per LDS chunk (3 tiles of 32)
-#define KM_ABUF (17 * 1024)      // bytes per staged chunk buffer (96 rows x 176 B, rounded up to whole wave-instructions)
+#define KM_PITCH 112            // LDS row pitch in bytes (28 dwords: 16 consecutive rows hit 16 distinct 4-bank groups)
+#define KM_SLOTS (KM_PITCH / 16)                  // 16-byte slots per staged row (6 data + 1 pad)
+#define KM_STAGE_INS ((KM_CHUNK * KM_SLOTS + 63) / 64)      // wave-instructions per staged chunk (11, the last one half used)
+#define KM_ABUF (KM_STAGE_INS * 1024)            // bytes per staged chunk buffer
 #define KM_NBUF 4                // ring of staged chunks: the DMA runs 3 chunks ahead of the MFMAs
-#define KM_PITCH 176            // LDS row pitch in bytes (44 dwords: 16 consecutive rows hit 16 distinct 4-bank groups)
 #define KM_EVROWS 32            // event entries (tile, 16-bit row mask) per lane, group and candidate cell
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
 #define KM_LIST_WORDS (2 * KM_EVROWS * 64)       // one event list: [group][entry][lane] uint32
-#define KM_T 1.7263349e-4f                       // t = 2^-12.5: split of the cross terms |q~||E_c|, |E_q||c| (see header)
-#define KM_ETA 2.44140625e-4f                    // eta = 2^-12: allowance for the f32 accumulation inside the matrix core
+#define KM_T 1.7263349e-4                        // t = 2^-12.5: split of the cross terms |y~_q||E_c|, |E_q||y_c| (see header)
+#define KM_ETA 2.44140625e-4                     // eta = 2^-12: allowance for the f32 accumulation inside the matrix core
 #define KM_MEAN_SAMPLES 1024
 
 struct KmGeom {
@@ -71,7 +88,7 @@ __device__ static inline size_t list_id(const KmGeom &a, int qcell, int qwave, i
 // ------------------------------------------------------------------------------------------------ prep
 // Candidate (image 2) rows are stored cell by cell in TILE POSITION order, every cell padded to whole chunks: position
 // (tile, row) of cell c holds candidate row * ntiles + tile of that cell (see the screen kernel), positions without a
-// candidate hold the sentinel row.  The screen then stages a chunk as one contiguous 15 KB read.
+// candidate hold the sentinel row.  The screen then stages a chunk as one contiguous 9 KB read.
 __host__ __device__ static inline int km_pad(int npts) { return (npts + KM_CHUNK - 1) / KM_CHUNK * KM_CHUNK; }
 __host__ __device__ static inline size_t km_cell_base(const Geom &g, int ci, int cj)
 {
@@ -107,10 +124,17 @@ __global__ void __launch_bounds__(1024) knn_mean_kernel(const float *__restrict_
     }
 }
 
+// f16 value not below v (v >= 0, below the f16 range): the factor exceeds one half-ulp of the rounding to nearest, the
+// constant the spacing of the subnormals
+__device__ static inline _Float16 km_f16_up(double v) { return (_Float16)(float)(v * 1.001 + 1e-7); }
+
 // which = 0: image 1 (queries), one thread per pixel, rows in pixel order.  which = 1: image 2 (candidates), one thread
-// per (cell = blockIdx.y, tile position), rows in position order (above).
-__global__ void knn_prep_kernel(const float *__restrict__ d, const float *__restrict__ mu, _Float16 *__restrict__ h,
-                                float2 *__restrict__ qs, int *__restrict__ flags, Geom g, int which)
+// per (cell = blockIdx.y, tile position), rows in position order (above).  The rotation y_j = sum_i V[j][i] x_i runs in
+// float64 (its rounding, 1e-14 |x|, is far below everything else in the bound); the components of V arrive through the
+// scalar cache (vt is wave-uniform), 8 components per iteration = one 16-byte store.
+__global__ void __launch_bounds__(256) knn_prep_kernel(const float *__restrict__ d, const float *__restrict__ mu,
+                                                       const double *__restrict__ vt, _Float16 *__restrict__ h,
+                                                       float2 *__restrict__ qs, int *__restrict__ flags, Geom g, int which)
 {
     int pix;
     size_t orow;
@@ -127,19 +151,20 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, const float *__rest
         const int ntiles = km_pad(cnpts) / 32;
         const int idx = (pos & 31) * ntiles + (pos >> 5);
         if (idx >= cnpts) {
-            // no candidate here: h- = h+ = 60000, everything else 0 -> MFMA value -60000, below every real one (real
-            // h +- S_c lie inside +-50000)
-            float4 *o = reinterpret_cast<float4 *>(h + orow * KM_K);
-            _Float16 z[8] = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
-            _Float16 t8[8] = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)60000.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)60000.0f};
-            for (int k = 0; k < KM_K * 2 / 16; k++) o[k] = *reinterpret_cast<const float4 *>(k == 8 ? t8 : z);   // k = 68 and 71
+            // no candidate here: h = 60000, everything else 0 -> MFMA value -60000 in both passes, below every real one
+            // (real h +- S_c lie inside +-50000) and below every threshold (>= -55000; no 1.0 here to subtract it)
+            half8 *o = reinterpret_cast<half8 *>(h + orow * KM_K);
+            half8 z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+            half8 t8 = z;
+            t8[KM_SLOT_H - 40] = (_Float16)60000.0f;
+            for (int k = 0; k < KM_K / 8; k++) o[k] = k == 5 ? t8 : z;
             return;
         }
         pix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
     }
     const float4 *s = reinterpret_cast<const float4 *>(d + (size_t)pix * DFLOW_DESC);
-    _Float16 row[KM_K];
-    float ss = 0.0f, sx = 0.0f, se = 0.0f;
+    double x[DFLOW_DESC];
+    double sxall = 0.0;
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < DFLOW_DESC / 4; k++) {
@@ -150,46 +175,63 @@ __global__ void knn_prep_kernel(const float *__restrict__ d, const float *__rest
             const float sc = KM_ALPHA * (e[j] - mu[4 * k + j]);   // one rounding (the subtraction); the scaling is exact
             // too large or NaN (tested on the bits: this file is compiled with -fno-honor-nans): no f16 representation
             bad |= (__float_as_uint(sc) & 0x7FFFFFFFu) >= 0x476A6000u;      // |sc| >= 60000, inf, NaN
-            const _Float16 hv = (_Float16)sc;
-            row[4 * k + j] = hv;
-            const float f = (float)hv, er = f - sc;    // exact: f and sc are within a factor of two of each other, or er = -sc
-            ss = ss + f * f;                           // |x~|^2
-            sx = sx + sc * sc;                         // |64 (x - mu)|^2 from the unrounded values
-            se = se + er * er;                         // |x~ - 64 (x - mu)|^2: the rounding error actually made
+            x[4 * k + j] = (double)sc;
+            sxall = fma(x[4 * k + j], x[4 * k + j], sxall);     // |x|^2 = |V^T x|^2 (1 +- 1e-9)
         }
     }
+    double ss = 0.0, sx = 0.0, se = 0.0;        // |y~|^2, |y_P|^2, |y~ - y_P|^2 over the KM_KD leading components
+    auto component = [&](int j) -> _Float16 {
+        const double *__restrict__ vj = vt + (size_t)j * DFLOW_DESC;
+        double y = 0.0;
 #pragma unroll
-    for (int k = DFLOW_DESC; k < KM_K; k++) row[k] = (_Float16)0.0f;
-    // Norms with their own float32 rounding (70 operations, relative < 1e-5) and the 2^-24 relative error of the
-    // subtraction (|E| <= sqrt(se) + 2^-24 sqrt(sx)) covered by the factors below.
-    const float ss_u = ss * 1.00002f, sx_u = sx * 1.00002f;
-    const float ee_u = (se + 1.2e-7f * sqrtf(se * sx) + 3.6e-15f * sx) * 1.00002f + 1e-30f;
-    if (which == 0) {
-        row[68] = (_Float16)-1.0f; row[69] = (_Float16)-1.0f; row[70] = (_Float16)-1.0f;   // pass-1 selectors (h-)
-        // S_q and 0.5 |q|^2 (upper bounds)
-        qs[pix] = make_float2((0.5f * KM_T * ss_u + ee_u * (0.5f / KM_T) + 0.5f * KM_ETA * ss_u) * 1.00001f, 0.5f * sx_u);
-    } else {
-        const float h = 0.5f * sx;
-        // S_c (upper bound) incl. eta h and the float32 rounding of h itself
-        // (the factor also covers eta S_c: the accumulation allowance is on |h +- S_c|, pieces included)
-        const float scs = (ee_u * (0.5f / KM_T) + 0.5f * KM_T * sx_u + KM_ETA * (0.5f * ss_u + h) + 2e-5f * h) * 1.0004f + 1e-6f;
-        bad |= h + scs >= 50000.0f || (__float_as_uint(h + scs) & 0x7FFFFFFFu) > 0x7F800000u;
-        // h- = h + S_c rounded up a little, h+ = h - S_c rounded down a little (the f16 triples carry 33 bits; pieces
-        // below the f16 subnormal range are lost: < 2^-24 absolute each)
-        const float hm = (h + scs) * 1.000001f + 1e-6f, hp = (h - scs) * (h > scs ? 0.999999f : 1.000001f) - 1e-6f;
-        float r = hm;
+        for (int i = 0; i < DFLOW_DESC; i++) y = fma(vj[i], x[i], y);
+        const float yf = (float)y;
+        bad |= (__float_as_uint(yf) & 0x7FFFFFFFu) >= 0x476A6000u;
+        const _Float16 hv = (_Float16)yf;
+        const double f = (double)(float)hv, er = f - y;
+        ss = fma(f, f, ss); sx = fma(y, y, sx); se = fma(er, er, se);
+        return hv;
+    };
+    half8 *o = reinterpret_cast<half8 *>(h + orow * KM_K);
+#pragma unroll 1
+    for (int jo = 0; jo < KM_KD / 8; jo++) {
+        half8 r;
 #pragma unroll
-        for (int i = 0; i < 3; i++) { _Float16 pc = (_Float16)r; row[68 + i] = pc; r = r - (float)pc; }
-        r = hp;
-#pragma unroll
-        for (int i = 0; i < 3; i++) { _Float16 pc = (_Float16)r; row[71 + i] = pc; r = r - (float)pc; }
-        // multipliers of the query's threshold pieces (pass 2 of the screen subtracts the threshold inside the MFMA)
-        row[74] = (_Float16)1.0f; row[75] = (_Float16)1.0f; row[76] = (_Float16)1.0f;
+        for (int j = 0; j < 8; j++) r[j] = component(8 * jo + j);
+        o[jo] = r;
     }
-    float4 *o = reinterpret_cast<float4 *>(h + orow * KM_K);
-    const float4 *r4 = reinterpret_cast<const float4 *>(row);
+    half8 last;
 #pragma unroll
-    for (int k = 0; k < KM_K * 2 / 16; k++) o[k] = r4[k];
+    for (int j = 8 * (KM_KD / 8); j < KM_KD; j++) last[j - 8 * (KM_KD / 8)] = component(j);
+    // |E| <= |y~ - y_P(computed)| + 6.2e-8 |x| (float32 rounding of d - mu, rotated; float64 rounding of the rotation);
+    // |y_D|^2 <= (1 + 1e-9)|x|^2 - |y_P|^2 (V orthonormal to 1e-9: knn_jacobi_kernel), same allowance on top
+    const double rx = sqrt(sxall);
+    double ee = sqrt(se) + 6.2e-8 * rx;
+    ee = ee * ee;
+    const double nd = sqrt(fmax(0.0, sxall * (1.0 + 2e-9) - sx)) + 6.2e-8 * rx;
+    const _Float16 n16 = km_f16_up(nd);
+    const double nn = (double)(float)n16;
+    last[KM_SLOT_N - 40] = n16;
+    if (which == 0) {
+        last[KM_SLOT_H - 40] = (_Float16)-1.0f; last[KM_SLOT_H + 1 - 40] = (_Float16)-1.0f;
+        last[KM_SLOT_S - 40] = (_Float16)-1.0f;
+        last[KM_SLOT_ONE - 40] = (_Float16)0.0f; last[KM_SLOT_ONE + 1 - 40] = (_Float16)0.0f;
+        // S_q and 0.5 |y_q|^2 (upper bounds, rounded up into float32)
+        const double sq = 0.5 * KM_T * ss + ee * (0.5 / KM_T) + 0.5 * KM_ETA * (ss + nn * nn);
+        qs[pix] = make_float2((float)(sq * 1.000001 + 1e-30), (float)(0.5 * sxall * 1.000002));
+    } else {
+        const double hh = 0.5 * sxall;
+        // S_c (upper bound); the factor also covers eta S_c (the accumulation allowance is on every product, S_c's too)
+        const double scs = (ee * (0.5 / KM_T) + 0.5 * KM_T * sx * (1.0 + 1e-9) + KM_ETA * (0.5 * ss + 0.5 * nn * nn + 1.001 * hh) + 2e-6 * hh) * 1.0004 + 1e-6;
+        const _Float16 s16 = km_f16_up(scs);
+        bad |= !(hh + (double)(float)s16 < 50000.0);
+        const _Float16 p1 = (_Float16)(float)hh;
+        const _Float16 p2 = (_Float16)(float)(hh - (double)(float)p1);
+        last[KM_SLOT_H - 40] = p1; last[KM_SLOT_H + 1 - 40] = p2;
+        last[KM_SLOT_S - 40] = s16;
+        last[KM_SLOT_ONE - 40] = (_Float16)1.0f; last[KM_SLOT_ONE + 1 - 40] = (_Float16)1.0f;
+    }
+    o[KM_K / 8 - 1] = last;
     if (bad) atomicOr(flags, 1);
 }
 
@@ -257,7 +299,7 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     (void)cx0; (void)cy0;
 
     // ---- my queries: group gq (0/1), column col; B fragments (last k-step differs between the passes) and slack
-    half8 bfrag[2][5], blast2[2];
+    half8 bfrag[2][KM_KSTEPS];
     float sq[2], hq[2];
 #pragma unroll
     for (int gq = 0; gq < 2; gq++) {
@@ -266,12 +308,10 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         const int qpix = (qy0 + qi / qcw) * g.W + qx0 + qi % qcw;
         const half8 *src = reinterpret_cast<const half8 *>(p.h1 + (size_t)qpix * KM_K);
 #pragma unroll
-        for (int s = 0; s < 5; s++) bfrag[gq][s] = src[2 * s + half];
-        // k = 64..71 sit in half 0, k = 72..79 in half 1: pass 1 selects h- (k = 68..70), pass 2 h+ (k = 71..73)
-        half8 b2 = bfrag[gq][4];
-        if (half == 0) { b2[4] = (_Float16)0.0f; b2[5] = (_Float16)0.0f; b2[6] = (_Float16)0.0f; b2[7] = (_Float16)-1.0f; }
-        else { b2[0] = (_Float16)-1.0f; b2[1] = (_Float16)-1.0f; }
-        blast2[gq] = b2;
+        for (int s = 0; s < KM_KSTEPS; s++) bfrag[gq][s] = src[2 * s + half];
+        // k = 40..47 sit in half 1 of the last k-step: y40, y41, n_q, -1, -1 (h), -1 (S_c), 0, 0 as stored.  Pass 1
+        // computes G^ - n_q n_c - h - S_c: the n slot changes sign
+        if (half == 1) bfrag[gq][KM_KSTEPS - 1][KM_SLOT_N - 40] = -bfrag[gq][KM_KSTEPS - 1][KM_SLOT_N - 40];
         const float2 qq = p.qs[qpix];
         sq[gq] = qq.x; hq[gq] = qq.y;
     }
@@ -279,19 +319,19 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     const int nchunks = (cnpts + KM_CHUNK - 1) / KM_CHUNK;
     const size_t cbase = km_cell_base(g, ci, cj);
     // Asynchronous staging of one chunk straight into LDS (global_load_lds_dwordx4: the LDS address is wave-uniform
-    // base + 16*lane, the global address is per lane).  The LDS image is 96 rows of 11 16-byte slots (10 data + 1
-    // pad = 176-byte pitch) = 1056 slots = 17 wave-instructions (the last one half used; the buffer is 17 KB).
+    // base + 16*lane, the global address is per lane).  The LDS image is 96 rows of 7 16-byte slots (6 data + 1
+    // pad = 112-byte pitch) = 672 slots = 11 wave-instructions (the last one half used; the buffer is 11 KB).
     // Pad slots re-read part 0; positions beyond the cell hold sentinel rows (MFMA value -60000 < every real one).
     auto stage = [&](int chunk, int buf) {
         char *base = abuf + (size_t)buf * KM_ABUF;
-        for (int ins = wave; ins < 17; ins += KM_WAVES) {
+        for (int ins = wave; ins < KM_STAGE_INS; ins += KM_WAVES) {
             const int slot = ins * 64 + lane;
-            int r = slot / 11, part = slot % 11;
+            int r = slot / KM_SLOTS, part = slot % KM_SLOTS;
             // the candidate rows are stored in tile position order (knn_prep_kernel): position p = (tile, row) holds
             // candidate row * ntiles + tile, so that the 16 rows a lane sees of one tile are far apart in the cell.
             // Neighbouring pixels have similar descriptors: with raster order several of a query's 5 best would share a
             // lane's tile column, of which only the maximum enters a5.
-            if (part > 9) part = 0;
+            if (part >= KM_K / 8) part = 0;
             const char *src = reinterpret_cast<const char *>(p.h2 + (cbase + (size_t)(min(chunk, nchunks - 1) * KM_CHUNK + r)) * KM_K) + part * 16;   // chunks staged past the end (never used) re-read the last one
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(base + ins * 1024), 16, 0, 0);
@@ -308,12 +348,12 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 #pragma unroll
         for (int i = 0; i < 5; i++) a5[gq][i] = -INFINITY;
 
-    // A wave issues n_w (2 for wave 0, else 1) DMA instructions per chunk, and in pass 2 exactly 6 event stores (one per tile and
+    // A wave issues n_w (2 for waves 0..2, else 1) DMA instructions per chunk, and in pass 2 exactly 6 event stores (one per tile and
     // column group, unconditionally: empty masks go to a scratch row).  Before the barrier that publishes chunk c+1 it
     // waits until only the DMAs of chunks c+2 and c+3 and the stores of chunks c-1 and c may still be in flight
     // (vmcnt counts all of them in issue order).  Chunks and tiles past the end of the cell are still staged/processed
     // (sentinel rows) so that these counts are exact.
-    const int n_w = (17 - wave + KM_WAVES - 1) / KM_WAVES;           // DMA instructions of this wave per chunk (1 or 2)
+    const int n_w = (KM_STAGE_INS - wave + KM_WAVES - 1) / KM_WAVES;           // DMA instructions of this wave per chunk (1 or 2)
     auto wait_ring = [&](int pass) {
         if (pass == 0) {
             if (n_w == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -349,35 +389,35 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 #pragma unroll 1
         for (int tile = 0; tile < KM_CHUNK / 32; tile++) {
             const int tileidx = chunk * (KM_CHUNK / 32) + tile;
-            half8 af[5];
+            half8 af[KM_KSTEPS];
             const char *arow = ab + (tile * 32 + col) * KM_PITCH + half * 16;
 #pragma unroll
-            for (int s = 0; s < 5; s++) af[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
+            for (int s = 0; s < KM_KSTEPS; s++) af[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
             __builtin_amdgcn_sched_barrier(0);
-            // unit (tile, group 0): its five MFMAs (one dependent chain, 32 cycles each) with the pending epilogue of
+            // unit (tile, group 0): its three MFMAs (one dependent chain, 32 cycles each) with the pending epilogue of
             // (previous tile, group 1) issued in their shadow, a few VALU per MFMA: the scheduler is told to build that
             // pipeline (sched_group_barrier) and not to mix the two halves (sched_barrier), otherwise it clusters the
             // MFMAs of both groups and the epilogues behind them, and the waves of a SIMD then alternate in lockstep
             // between matrix-only and vector-only phases (matrix pipe 55 % busy)
             f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 5; s++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[0][s], acc0, 0, 0, 0);
+            for (int s = 0; s < KM_KSTEPS; s++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[0][s], acc0, 0, 0, 0);
             if (PASS == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile);
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < KM_KSTEPS; s++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 3 : 5, 0);   // VALU of the epilogue in its shadow
+                __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 5 : 7, 0);   // VALU of the epilogue in its shadow
             }
             __builtin_amdgcn_sched_barrier(0);
             // unit (tile, group 1): MFMAs, in their shadow the epilogue of (tile, group 0)
             f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 5; s++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[1][s], acc1, 0, 0, 0);
+            for (int s = 0; s < KM_KSTEPS; s++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[1][s], acc1, 0, 0, 0);
             if (PASS == 0) epi1(acc0, 0); else epi2(acc0, 0, tileidx);
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < KM_KSTEPS; s++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 3 : 5, 1);
+                __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 5 : 7, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
             pend = acc1; pend_tile = tileidx;
@@ -413,20 +453,23 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 #pragma unroll
                 for (int i = 0; i < 5; i++) top5_insert_desc(a5[gq], o[i]);
                 const float a5v = a5[gq][4];
-                const float x = a5v - 2.0f * sq[gq] - 2.2e-5f * (hq[gq] - a5v + sq[gq]);
+                const float x = a5v - 2.0f * sq[gq] - 2.3e-5f * (hq[gq] - a5v + sq[gq]);
                 const float th = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -55000.0f);   // real values are > -50000, sentinel rows -60000
-                // Pass 2 subtracts the threshold inside the matrix core: three f16 pieces of th' (33 bits) times the 1.0 the
-                // candidate rows carry at k = 74..76.  th' lies below th by the accumulation allowance eta on the three extra
-                // products (|pieces| <= |th'|) and by more than the pieces' truncation (< 2^-24 absolute each), so
-                // v >= th implies a computed v - th' >= 0; sentinel rows (-60000, no 1.0) stay negative.
+                // Pass 2 subtracts the threshold inside the matrix core: two f16 pieces of th' (22 bits) times the 1.0 the
+                // candidate rows carry at k = 46, 47.  th' lies below th by the accumulation allowance eta on the two extra
+                // products (|pieces| <= 1.001 |th'|) and by more than the pieces' truncation (2^-22 relative, < 2^-24
+                // absolute in the subnormal range), so v >= th implies a computed v - th' >= 0; sentinel rows (-60000, no
+                // 1.0) stay negative.  The n slot and the S_c selector change sign: v = G^ + n_q n_c - h + S_c.
                 const float thp = th - 2.6e-4f * fabsf(th) - 1e-5f;
-                half8 b2 = blast2[gq];                                          // pass 2 selects h+
                 if (half == 1) {
-                    float r = thp;
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { const _Float16 pc = (_Float16)r; b2[2 + i] = -pc; r = r - (float)pc; }
+                    half8 b2 = bfrag[gq][KM_KSTEPS - 1];
+                    b2[KM_SLOT_N - 40] = -b2[KM_SLOT_N - 40];
+                    b2[KM_SLOT_S - 40] = (_Float16)1.0f;
+                    const _Float16 p1 = (_Float16)thp;
+                    const _Float16 p2 = (_Float16)(thp - (float)p1);
+                    b2[KM_SLOT_ONE - 40] = -p1; b2[KM_SLOT_ONE + 1 - 40] = -p2;
+                    bfrag[gq][KM_KSTEPS - 1] = b2;
                 }
-                bfrag[gq][4] = b2;
             }
         }
     }

@@ -87,6 +87,10 @@ class DiscreteFlow:
         self.descrs1.copy_(torch.as_tensor(descrs1, dtype=torch.float32))
         self.descrs2.copy_(torch.as_tensor(descrs2, dtype=torch.float32))
 
+    def descriptors_f32(self, which):
+        """Descriptors of image `which` (0: first, 1: second) as an (H,W,68) float32 tensor, whatever the storage."""
+        return (self.descrs1, self.descrs2)[which].to(torch.float32)
+
     def generisi(self):
         """napraviCD2 + generisi, daisy i flann.py:144-189."""
         self._bcd_ready = False
