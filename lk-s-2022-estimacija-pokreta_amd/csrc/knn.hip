@@ -132,18 +132,34 @@ __global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, co
 
 // Fix-up for the MFMA path.  Work item = (query cell, first query index, 64 queries, candidate cell).  Items come
 // from the overflow list, or -- if the prep kernel flagged out-of-range descriptors or the list itself overflowed --
-// every item of the pass is enumerated.  Blocks of one wave walk the items grid-stride.
-__global__ void __launch_bounds__(64, 4) knn_fix_kernel(KnnArgs a, const float *__restrict__ gd1, const float *__restrict__ gd2,
+// every item of the pass is enumerated.  A workgroup of KNN_FIX_WAVES waves takes one item at a time (grid-stride): all
+// waves hold the same 64 queries (lane = query), wave w scans every KNN_FIX_WAVES-th ROW of the candidate cell, the partial
+// top-5 lists meet in LDS and wave 0 merges them in row order with the insertion rule of the scan (strict '<': equal
+// distances stay in index order), so the result is that of one sequential scan.  A single overflowed list used to cost
+// the latency of one wave walking a whole cell (1.3 ms at 64x27 cells); split over 16 waves it costs 0.1 ms.
+#define KNN_FIX_WAVES 16
+__device__ static inline void top5_insert(Top5 &t, float cd, int cidx)
+{
+    bool sh = false;
+#define CSWAP(D, I) if (sh || cd < D) { float td = D; int ti = I; D = cd; I = cidx; cd = td; cidx = ti; sh = true; }
+    CSWAP(t.d0, t.i0) CSWAP(t.d1, t.i1) CSWAP(t.d2, t.i2) CSWAP(t.d3, t.i3) CSWAP(t.d4, t.i4)
+#undef CSWAP
+}
+
+__global__ void __launch_bounds__(64 * KNN_FIX_WAVES) knn_fix_kernel(KnnArgs a, const float *__restrict__ gd1, const float *__restrict__ gd2,
                                                         uint32_t *__restrict__ gproposals, float *__restrict__ glcosts,
                                                         const int *__restrict__ ovf_count, const int4 *__restrict__ ovf_list,
                                                         int ovf_cap, const int *__restrict__ flags, int qwaves)
 {
+    __shared__ float pd[KNN_FIX_WAVES][5][64];
+    __shared__ int pi[KNN_FIX_WAVES][5][64];
     const Geom g = a.g;
     const int win = 2 * g.win + 1;
     const int nov = *ovf_count;
     const bool all = (*flags != 0) || nov > ovf_cap;
     const int total = all ? g.ncx * g.ncy * qwaves * win * win : nov;
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {       // block-uniform: barriers inside are safe
         int qcell, qstart, ci, cj;
         if (all) {
             int b = item;
@@ -161,7 +177,7 @@ __global__ void __launch_bounds__(64, 4) knn_fix_kernel(KnnArgs a, const float *
         const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
         const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0, qnpts = qcw * (g.y1(qcj) - qy0);
         if (qstart >= qnpts) continue;
-        int qi = qstart + threadIdx.x;
+        int qi = qstart + lane;
         const bool active = qi < qnpts;
         if (!active) qi = qnpts - 1;
         const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
@@ -170,10 +186,49 @@ __global__ void __launch_bounds__(64, 4) knn_fix_kernel(KnnArgs a, const float *
         const int slot = 5 * ((ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin));
         float q[DFLOW_DESC];
         load_query(q, gd1, pix);
+        // ---- this wave's rows of the candidate cell
+        const int cx0 = g.x0(ci), cy0 = g.y0(cj), cy1 = g.y1(cj), ccw = g.x1(ci) - cx0;
         Top5 t;
-        search_cell_exact(q, gd2, g, ci, cj, t);
-        float c[5];
-        emit_cell(t, g, ci, cj, pix, qy, qx, slot, a.LP, a.tphi, active, gd1, gd2, gproposals, glcosts, c);
+        t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
+        t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
+        for (int yy = cy0 + wave; yy < cy1; yy += KNN_FIX_WAVES) {
+            const float4 *__restrict__ row = reinterpret_cast<const float4 *>(gd2 + ((size_t)yy * g.W + cx0) * DFLOW_DESC);
+            for (int xx = 0; xx < ccw; xx++) {
+                const float4 *__restrict__ c = row + xx * (DFLOW_DESC / 4);   // wave-uniform address
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < DFLOW_DESC / 4; k++) {
+                    float4 v = c[k];
+                    float e;
+                    e = q[4 * k] - v.x; acc = __fmaf_rn(e, e, acc);
+                    e = q[4 * k + 1] - v.y; acc = __fmaf_rn(e, e, acc);
+                    e = q[4 * k + 2] - v.z; acc = __fmaf_rn(e, e, acc);
+                    e = q[4 * k + 3] - v.w; acc = __fmaf_rn(e, e, acc);
+                }
+                if (acc < t.d4) top5_insert(t, acc, (yy - cy0) * ccw + xx);
+            }
+        }
+        pd[wave][0][lane] = t.d0; pd[wave][1][lane] = t.d1; pd[wave][2][lane] = t.d2; pd[wave][3][lane] = t.d3; pd[wave][4][lane] = t.d4;
+        pi[wave][0][lane] = t.i0; pi[wave][1][lane] = t.i1; pi[wave][2][lane] = t.i2; pi[wave][3][lane] = t.i3; pi[wave][4][lane] = t.i4;
+        __syncthreads();
+        if (wave == 0) {
+            // Merge.  The sequential scan orders equal distances by index; here entries arrive wave by wave, so the rule is
+            // applied on (distance, index) explicitly: an entry goes in front of a slot iff its distance is smaller, or equal
+            // with a smaller index.  Slots still at their initial (inf, 0) hold no candidate and are skipped.
+            for (int w = 1; w < KNN_FIX_WAVES; w++)
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    float cd = pd[w][j][lane]; int cidx = pi[w][j][lane];
+                    if (!(cd < INFINITY)) continue;
+                    bool sh = false;
+#define CSWAP(D, I) if (sh || cd < D || (cd == D && cidx < I)) { float td = D; int ti = I; D = cd; I = cidx; cd = td; cidx = ti; sh = true; }
+                    CSWAP(t.d0, t.i0) CSWAP(t.d1, t.i1) CSWAP(t.d2, t.i2) CSWAP(t.d3, t.i3) CSWAP(t.d4, t.i4)
+#undef CSWAP
+                }
+            float c[5];
+            emit_cell(t, g, ci, cj, pix, qy, qx, slot, a.LP, a.tphi, active, gd1, gd2, gproposals, glcosts, c);
+        }
+        __syncthreads();
     }
 }
 
@@ -198,7 +253,7 @@ int launch_knn_fix(const dflow_params *p, const float *d1, const float *d2, uint
     a.LP = p->label_pitch; a.tphi = p->tphi; a.chunks = 0;
     int maxpts = (a.g.x1(a.g.ncx - 1) - a.g.x0(a.g.ncx - 1)) * (a.g.y1(a.g.ncy - 1) - a.g.y0(a.g.ncy - 1));
     int qwaves = (maxpts + 63) / 64;
-    hipLaunchKernelGGL(knn_fix_kernel, dim3(4096), dim3(64), 0, s, a, d1, d2, proposals, lcosts, ovf_count, ovf_list, ovf_cap,
+    hipLaunchKernelGGL(knn_fix_kernel, dim3(1024), dim3(64 * KNN_FIX_WAVES), 0, s, a, d1, d2, proposals, lcosts, ovf_count, ovf_list, ovf_cap,
                        flags, qwaves);
     return dflow_check_launch("knn_fix_kernel");
 }

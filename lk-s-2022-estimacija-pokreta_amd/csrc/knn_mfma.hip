@@ -5,21 +5,22 @@
 // evaluated one by one:
 //
 //   basis     a fixed centre mu (mean descriptor of a pixel sample, knn_mean_kernel) and the principal axes V of a sample
-//             of image-2 descriptors (knn_pca.hip, float64).  x = 64 (d - mu), y = V^T x: distances do not change
-//             (V orthonormal to 1e-9, measured), the products get smaller, and the energy of y collects in its leading
+//             of image-2 descriptors (knn_pca.hip).  x = 64 (d - mu), y = V^T x: distances do not change
+//             (V orthonormal to 2e-6, measured), the products get smaller, and the energy of y collects in its leading
 //             components: the screen multiplies the first KM_KD = 42 of them (y_P) and bounds the product of the dropped 26
 //             (y_D) by Cauchy-Schwarz, |y_D(q) . y_D(c)| <= n_q n_c with n >= |y_D|.
 //   prep      (knn_prep_kernel) both images become rows of KM_K = 48 f16: y~ = f16(y_P), then for image 2 n_c, two f16
 //             pieces of h = 0.5 |x_c|^2, the candidate's share S_c of the error bound and two 1.0; for image 1 n_q and the
 //             matching selectors.  With G^ = the MFMA's value of y~_q . y~_c (exact products, f32 accumulation) and
-//             E = y~ - y_P the rounding errors actually made (their norms are computed here in float64, nothing is assumed
-//             about f16 rounding),
+//             E = y~ - y_P the rounding errors actually made (the f16 part is measured, nothing is assumed about f16
+//             rounding; the float32 rotation enters with its worst-case bound KM_RHO |x|),
 //                 |y_P(q) . y_P(c) - G^| <= |y~_q||E_c| + |E_q||y_P(c)| + eta (sum of |products|)  <=  S_c + S_q,
 //                 S_c = |E_c|^2/(2t) + (t/2)|y_P(c)|^2 + eta (|y~_c|^2/2 + n_c^2/2 + h) + 2e-6 h,
 //                 S_q = (t/2)|y~_q|^2 + |E_q|^2/(2t) + (eta/2)(|y~_q|^2 + n_q^2)
-//             (t = 2^-12.5; eta = 2^-12 bounds the f32 accumulation of the 48 products inside the matrix core, about 40
-//             times what IEEE summation would need; 2e-6 h covers the two-piece representation of h, |V^T V - I| and the
-//             float32 rounding of d - mu), so tau = y_q . y_c - 0.5 |y_c|^2 = 0.5 (|y_q|^2 - |y_q - y_c|^2) lies within
+//             (t = 2^-12.5; eta = 2^-17 bounds the f32 accumulation of the 48 exact products inside the matrix core: it
+//             holds for ANY order of the additions and any rounding mode with at most one ulp (2^-23) per addition, up to 64
+//             terms; measured on gfx950, scratch/ubench/mfma_err.hip: <= 2^-20.7 at K = 80 over six operand distributions;
+//             2e-6 h covers the two-piece representation of h, |V^T V - I| and the float32 rounding of d - mu), so tau = y_q . y_c - 0.5 |y_c|^2 = 0.5 (|y_q|^2 - |y_q - y_c|^2) lies within
 //             n_q n_c + S_c + S_q of G^ - h.
 //   screen    (knn_screen_kernel) pass 1: w = G^ - n_q n_c - h - S_c for every (query, candidate) of a (64-query wave,
 //             candidate cell); w - S_q <= tau.  Every lane keeps the 5 largest maxima of its 16-value tile columns -> a5,
@@ -69,7 +70,7 @@ template <int V> struct KmC { static constexpr int value = V; };
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
 #define KM_LIST_WORDS (2 * KM_EVROWS * 64)       // one event list: [group][entry][lane] uint32
 #define KM_T 1.7263349e-4                        // t = 2^-12.5: split of the cross terms |y~_q||E_c|, |E_q||y_c| (see header)
-#define KM_ETA 2.44140625e-4                     // eta = 2^-12: allowance for the f32 accumulation inside the matrix core
+#define KM_ETA 7.62939453125e-6                  // eta = 2^-17: allowance for the f32 accumulation inside the matrix core
 #define KM_MEAN_SAMPLES 1024
 
 struct KmGeom {
@@ -129,11 +130,13 @@ __global__ void __launch_bounds__(1024) knn_mean_kernel(const float *__restrict_
 __device__ static inline _Float16 km_f16_up(double v) { return (_Float16)(float)(v * 1.001 + 1e-7); }
 
 // which = 0: image 1 (queries), one thread per pixel, rows in pixel order.  which = 1: image 2 (candidates), one thread
-// per (cell = blockIdx.y, tile position), rows in position order (above).  The rotation y_j = sum_i V[j][i] x_i runs in
-// float64 (its rounding, 1e-14 |x|, is far below everything else in the bound); the components of V arrive through the
-// scalar cache (vt is wave-uniform), 8 components per iteration = one 16-byte store.
+// per (cell = blockIdx.y, tile position), rows in position order (above).  The rotation y_j = sum_i V[j][i] x_i is a float32
+// fmaf chain; the components of V arrive through the scalar cache (vt is wave-uniform), 8 components per iteration = one
+// 16-byte store.  Its rounding is part of E: |y^_j - y_j| <= gamma_68 sum_i |V_ji x_i| <= 68 * 2^-24 (1 + 5e-6) |x|, over
+// the 42 components |y^ - y_P| <= 2.63e-5 |x| (KM_RHO also holds the 6.2e-8 |x| of the rounding of d - mu).
+#define KM_RHO 2.65e-5
 __global__ void __launch_bounds__(256) knn_prep_kernel(const float *__restrict__ d, const float *__restrict__ mu,
-                                                       const double *__restrict__ vt, _Float16 *__restrict__ h,
+                                                       const float *__restrict__ vt, _Float16 *__restrict__ h,
                                                        float2 *__restrict__ qs, int *__restrict__ flags, Geom g, int which)
 {
     int pix;
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const float *__restrict__
         pix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
     }
     const float4 *s = reinterpret_cast<const float4 *>(d + (size_t)pix * DFLOW_DESC);
-    double x[DFLOW_DESC];
+    float x[DFLOW_DESC];
     double sxall = 0.0;
     bool bad = false;
 #pragma unroll
@@ -175,21 +178,20 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const float *__restrict__
             const float sc = KM_ALPHA * (e[j] - mu[4 * k + j]);   // one rounding (the subtraction); the scaling is exact
             // too large or NaN (tested on the bits: this file is compiled with -fno-honor-nans): no f16 representation
             bad |= (__float_as_uint(sc) & 0x7FFFFFFFu) >= 0x476A6000u;      // |sc| >= 60000, inf, NaN
-            x[4 * k + j] = (double)sc;
-            sxall = fma(x[4 * k + j], x[4 * k + j], sxall);     // |x|^2 = |V^T x|^2 (1 +- 1e-9)
+            x[4 * k + j] = sc;
+            sxall = fma((double)sc, (double)sc, sxall);          // |x|^2; |V^T x|^2 = |x|^2 (1 +- PCA_DELTA_MAX)
         }
     }
-    double ss = 0.0, sx = 0.0, se = 0.0;        // |y~|^2, |y_P|^2, |y~ - y_P|^2 over the KM_KD leading components
+    double ss = 0.0, sx = 0.0, se = 0.0;        // |y~|^2, |y^|^2, |y~ - y^|^2 over the KM_KD leading components
     auto component = [&](int j) -> _Float16 {
-        const double *__restrict__ vj = vt + (size_t)j * DFLOW_DESC;
-        double y = 0.0;
+        const float *__restrict__ vj = vt + (size_t)j * DFLOW_DESC;
+        float y = 0.0f;
 #pragma unroll
-        for (int i = 0; i < DFLOW_DESC; i++) y = fma(vj[i], x[i], y);
-        const float yf = (float)y;
-        bad |= (__float_as_uint(yf) & 0x7FFFFFFFu) >= 0x476A6000u;
-        const _Float16 hv = (_Float16)yf;
-        const double f = (double)(float)hv, er = f - y;
-        ss = fma(f, f, ss); sx = fma(y, y, sx); se = fma(er, er, se);
+        for (int i = 0; i < DFLOW_DESC; i++) y = __fmaf_rn(vj[i], x[i], y);
+        bad |= (__float_as_uint(y) & 0x7FFFFFFFu) >= 0x476A6000u;
+        const _Float16 hv = (_Float16)y;
+        const double f = (double)(float)hv, yd = (double)y, er = f - yd;
+        ss = fma(f, f, ss); sx = fma(yd, yd, sx); se = fma(er, er, se);
         return hv;
     };
     half8 *o = reinterpret_cast<half8 *>(h + orow * KM_K);
@@ -203,12 +205,13 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const float *__restrict__
     half8 last;
 #pragma unroll
     for (int j = 8 * (KM_KD / 8); j < KM_KD; j++) last[j - 8 * (KM_KD / 8)] = component(j);
-    // |E| <= |y~ - y_P(computed)| + 6.2e-8 |x| (float32 rounding of d - mu, rotated; float64 rounding of the rotation);
-    // |y_D|^2 <= (1 + 1e-9)|x|^2 - |y_P|^2 (V orthonormal to 1e-9: knn_jacobi_kernel), same allowance on top
-    const double rx = sqrt(sxall);
-    double ee = sqrt(se) + 6.2e-8 * rx;
+    // E = y~ - y_P: |E| <= |y~ - y^| + KM_RHO |x|;  |y_P| <= |y^| + KM_RHO |x|;
+    // |y_D|^2 = |y|^2 - |y_P|^2 <= (1 + delta)|x|^2 - (|y^| - KM_RHO |x|)^2
+    const double rx = sqrt(sxall), ry = sqrt(sx);
+    double ee = sqrt(se) + KM_RHO * rx;
     ee = ee * ee;
-    const double nd = sqrt(fmax(0.0, sxall * (1.0 + 2e-9) - sx)) + 6.2e-8 * rx;
+    const double ypl = fmax(0.0, ry - KM_RHO * rx), ypu = ry + KM_RHO * rx;
+    const double nd = sqrt(fmax(0.0, sxall * (1.0 + 1.1 * PCA_DELTA_MAX) - ypl * ypl));
     const _Float16 n16 = km_f16_up(nd);
     const double nn = (double)(float)n16;
     last[KM_SLOT_N - 40] = n16;
@@ -218,11 +221,12 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const float *__restrict__
         last[KM_SLOT_ONE - 40] = (_Float16)0.0f; last[KM_SLOT_ONE + 1 - 40] = (_Float16)0.0f;
         // S_q and 0.5 |y_q|^2 (upper bounds, rounded up into float32)
         const double sq = 0.5 * KM_T * ss + ee * (0.5 / KM_T) + 0.5 * KM_ETA * (ss + nn * nn);
-        qs[pix] = make_float2((float)(sq * 1.000001 + 1e-30), (float)(0.5 * sxall * 1.000002));
+        qs[pix] = make_float2((float)(sq * 1.000001 + 1e-30), (float)(0.5 * sxall * (1.0 + 1.5 * PCA_DELTA_MAX)));
     } else {
         const double hh = 0.5 * sxall;
-        // S_c (upper bound); the factor also covers eta S_c (the accumulation allowance is on every product, S_c's too)
-        const double scs = (ee * (0.5 / KM_T) + 0.5 * KM_T * sx * (1.0 + 1e-9) + KM_ETA * (0.5 * ss + 0.5 * nn * nn + 1.001 * hh) + 2e-6 * hh) * 1.0004 + 1e-6;
+        // S_c (upper bound); the factor also covers eta S_c (the accumulation allowance is on every product, S_c's too);
+        // 3e-6 h: |0.5 |y_c|^2 - h| <= delta h, the float32 rounding of d - mu (1.2e-7 h) and the two-piece form of h (2.4e-7 h)
+        const double scs = (ee * (0.5 / KM_T) + 0.5 * KM_T * ypu * ypu + KM_ETA * (0.5 * ss + 0.5 * nn * nn + 1.001 * hh) + 3e-6 * hh) * 1.0004 + 1e-6;
         const _Float16 s16 = km_f16_up(scs);
         bad |= !(hh + (double)(float)s16 < 50000.0);
         const _Float16 p1 = (_Float16)(float)hh;
@@ -322,26 +326,38 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     // base + 16*lane, the global address is per lane).  The LDS image is 96 rows of 7 16-byte slots (6 data + 1
     // pad = 112-byte pitch) = 672 slots = 11 wave-instructions (the last one half used; the buffer is 11 KB).
     // Pad slots re-read part 0; positions beyond the cell hold sentinel rows (MFMA value -60000 < every real one).
+    // the byte offsets of this wave's (at most two) DMA instructions inside a chunk do not depend on the chunk: computed
+    // once; per chunk only the scalar base moves (scalar base + 32-bit lane offset addressing)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    uint32_t soff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int slot = (wave_u + i * KM_WAVES) * 64 + lane;
+        // the candidate rows are stored in tile position order (knn_prep_kernel): position p = (tile, row) holds
+        // candidate row * ntiles + tile, so that the 16 rows a lane sees of one tile are far apart in the cell.
+        // Neighbouring pixels have similar descriptors: with raster order several of a query's 5 best would share a
+        // lane's tile column, of which only the maximum enters a5.
+        int part = slot % KM_SLOTS;
+        if (part >= KM_K / 8) part = 0;
+        soff[i] = (uint32_t)((slot / KM_SLOTS) * (KM_K * 2) + part * 16);
+    }
+    const rs_gptr h2cell = (rs_gptr)(p.h2 + cbase * KM_K);
+    const int n_w = (KM_STAGE_INS - wave_u + KM_WAVES - 1) / KM_WAVES;           // DMA instructions of this wave per chunk (1 or 2)
     auto stage = [&](int chunk, int buf) {
-        char *base = abuf + (size_t)buf * KM_ABUF;
-        for (int ins = wave; ins < KM_STAGE_INS; ins += KM_WAVES) {
-            const int slot = ins * 64 + lane;
-            int r = slot / KM_SLOTS, part = slot % KM_SLOTS;
-            // the candidate rows are stored in tile position order (knn_prep_kernel): position p = (tile, row) holds
-            // candidate row * ntiles + tile, so that the 16 rows a lane sees of one tile are far apart in the cell.
-            // Neighbouring pixels have similar descriptors: with raster order several of a query's 5 best would share a
-            // lane's tile column, of which only the maximum enters a5.
-            if (part >= KM_K / 8) part = 0;
-            const char *src = reinterpret_cast<const char *>(p.h2 + (cbase + (size_t)(min(chunk, nchunks - 1) * KM_CHUNK + r)) * KM_K) + part * 16;   // chunks staged past the end (never used) re-read the last one
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(base + ins * 1024), 16, 0, 0);
-        }
+        char *base = abuf + (size_t)buf * KM_ABUF + wave_u * 1024;
+        const rs_gptr src = h2cell + (size_t)min(chunk, nchunks - 1) * (KM_CHUNK * KM_K * 2);   // chunks staged past the end (never used) re-read the last one
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + soff[0]),
+                                         (__attribute__((address_space(3))) void *)base, 16, 0, 0);
+        if (n_w == 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + soff[1]),
+                                             (__attribute__((address_space(3))) void *)(base + KM_WAVES * 1024), 16, 0, 0);
     };
 
     float a5[2][5];
     int cnt[2] = {0, 0};
+    const uint32_t evoff[2] = {(uint32_t)lane * 4u, (uint32_t)lane * 4u + KM_EVROWS * 256u};
     const size_t lid = list_id(a, qcell, qwave, wslot);
-    uint32_t *myev = p.ev + lid * KM_LIST_WORDS + lane;
+    const rs_gptr evlist = (rs_gptr)(p.ev + lid * KM_LIST_WORDS);       // wave-uniform; entry (gq, row) of a lane at 4 lane + 256 (32 gq + row)
 
 #pragma unroll
     for (int gq = 0; gq < 2; gq++)
@@ -353,7 +369,6 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     // waits until only the DMAs of chunks c+2 and c+3 and the stores of chunks c-1 and c may still be in flight
     // (vmcnt counts all of them in issue order).  Chunks and tiles past the end of the cell are still staged/processed
     // (sentinel rows) so that these counts are exact.
-    const int n_w = (KM_STAGE_INS - wave + KM_WAVES - 1) / KM_WAVES;           // DMA instructions of this wave per chunk (1 or 2)
     auto wait_ring = [&](int pass) {
         if (pass == 0) {
             if (n_w == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -366,17 +381,19 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     // Pass 2: 16-bit mask of the rows that qualify (bit r <-> accumulator register r) -> one event word.
     auto epi1 = [&](const f32x16 &acc, int gq) { top5_insert_desc(a5[gq], max16(acc)); };
     auto epi2 = [&](const f32x16 &acc, int gq, int tileidx) {
-        // pass 2 accumulates v - th' (the threshold rides in the k = 74..76 products), so a row qualifies iff its
-        // accumulator is not negative: one v_alignbit per row shifts the sign bit into the mask (bit r <-> register r)
+        // pass 2 accumulates v - th' (the threshold rides in the k = 46, 47 products), so a row qualifies iff its
+        // accumulator is not negative: one v_alignbit per row shifts the sign bit into the word (bit r <-> register r)
         uint32_t neg = 0u;
 #pragma unroll
         for (int r = 15; r >= 0; r--) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(acc[r]), 31);
-        const uint32_t mask = ~neg & 0xFFFFu;
-        // always one store: real entries go to row cnt, empty masks to the scratch row KM_EVROWS-1 (a list that needs
-        // that row for data is reported as overflowed)
-        const int row = mask ? min(cnt[gq], KM_EVROWS - 1) : KM_EVROWS - 1;
-        myev[(size_t)(gq * KM_EVROWS + row) * 64] = ((uint32_t)tileidx << 16) | mask;
-        cnt[gq] += mask ? 1 : 0;
+        // entry = (tile << 16) | (~neg & 0xFFFF) = neg ^ ((tile << 16) | 0xFFFF).  Always one store (the vmcnt bookkeeping of
+        // the ring counts on it), to entry cnt of the lane's list; cnt only advances past entries with a mask, so an
+        // empty one is overwritten by the next (same lane, same address: in order) or stays behind the end of the list.
+        // Entry KM_EVROWS-1 is never valid: a list that reaches it is reported as overflowed.
+        const uint32_t off = evoff[gq] + ((uint32_t)min(cnt[gq], KM_EVROWS - 1) << 8);
+        *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(const_cast<__attribute__((address_space(1))) char *>(evlist) + off) =
+            neg ^ (((uint32_t)tileidx << 16) | 0xFFFFu);
+        cnt[gq] += neg != 0xFFFFu ? 1 : 0;
     };
     // the pipeline starts with a harmless unit: -inf never enters a top-5 (pass 1) and is negative (pass 2)
     const f32x16 minus_inf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY,
@@ -444,7 +461,8 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         __builtin_amdgcn_s_barrier();
         if (pass == 0) {
             // merge the two half-lanes of every query; pass-2 values v qualify iff v >= a5 - 2 S_q - s, where s covers the
-            // rounding of the canonical float32 distance: relative < 1.1e-5 of 64^2 d^2 / 2 = 0.5|q|^2 - tau <= hq - (a5 - S_q)
+            // rounding of the canonical float32 distance (relative < 1.1e-5) and |y_q - y_c|^2 = |x_q - x_c|^2 (1 +- 2e-6): twice
+            // 1.35e-5 of 64^2 d^2 / 2 = 0.5|q|^2 - tau <= hq - (a5 - S_q)
 #pragma unroll
             for (int gq = 0; gq < 2; gq++) {
                 float o[5];
@@ -453,14 +471,14 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 #pragma unroll
                 for (int i = 0; i < 5; i++) top5_insert_desc(a5[gq], o[i]);
                 const float a5v = a5[gq][4];
-                const float x = a5v - 2.0f * sq[gq] - 2.3e-5f * (hq[gq] - a5v + sq[gq]);
+                const float x = a5v - 2.0f * sq[gq] - 2.7e-5f * (hq[gq] - a5v + sq[gq]);
                 const float th = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -55000.0f);   // real values are > -50000, sentinel rows -60000
                 // Pass 2 subtracts the threshold inside the matrix core: two f16 pieces of th' (22 bits) times the 1.0 the
-                // candidate rows carry at k = 46, 47.  th' lies below th by the accumulation allowance eta on the two extra
-                // products (|pieces| <= 1.001 |th'|) and by more than the pieces' truncation (2^-22 relative, < 2^-24
+                // candidate rows carry at k = 46, 47.  th' lies below th by the accumulation allowance eta = 7.7e-6 on the two extra
+                // products (|pieces| <= 1.001 |th'|) and by more than the pieces' truncation (2^-22 = 2.4e-7 relative, < 2^-24
                 // absolute in the subnormal range), so v >= th implies a computed v - th' >= 0; sentinel rows (-60000, no
                 // 1.0) stay negative.  The n slot and the S_c selector change sign: v = G^ + n_q n_c - h + S_c.
-                const float thp = th - 2.6e-4f * fabsf(th) - 1e-5f;
+                const float thp = th - 1e-5f * fabsf(th) - 1e-5f;
                 if (half == 1) {
                     half8 b2 = bfrag[gq][KM_KSTEPS - 1];
                     b2[KM_SLOT_N - 40] = -b2[KM_SLOT_N - 40];
@@ -724,6 +742,7 @@ size_t knn_mfma_ws_bytes(const dflow_params *p)
     size_t N = (size_t)p->pich * p->picw;
     size_t nl = num_lists(p);
     return (N + km_total_rows(make_geom(p))) * KM_K * sizeof(_Float16) + N * sizeof(float2) + 1024 +
+           DFLOW_DESC * DFLOW_DESC * sizeof(double) + knn_pca_ws_bytes() + 512 +
            KM_OVF_CAP * sizeof(int4) + nl * (KM_LIST_WORDS * sizeof(uint32_t) + 128) + 1024;
 }
 
@@ -749,6 +768,9 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     w = align256(w);
     int *ctr = (int *)w; w += 256;              // ctr[0] = overflow count, ctr[1] = flags
     float *mu = (float *)w; w += 512;           // centre of the screen's coordinates
+    float *vt = (float *)w; w += DFLOW_DESC * DFLOW_DESC * sizeof(double);     // principal axes, [component][dimension]
+    w = align256(w);
+    void *pca_ws = w; w += knn_pca_ws_bytes();
     int4 *ovf = (int4 *)w; w += KM_OVF_CAP * sizeof(int4);
     w = align256(w);
     uint32_t *ev = (uint32_t *)w; w += nl * KM_LIST_WORDS * sizeof(uint32_t);
@@ -757,9 +779,11 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
         return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_knn_mfma");
     int nb = (int)((N + 255) / 256);
     hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(1024), 0, s, d2, mu, (int)N);
-    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, (const float *)mu, h1, qs, ctr + 1, g, 0);
+    int rc = launch_knn_pca(d2, mu, vt, ctr + 1, pca_ws, (int)N, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, (const float *)mu, (const float *)vt, h1, qs, ctr + 1, g, 0);
     hipLaunchKernelGGL(knn_prep_kernel, dim3((km_pad(max_cell_points(g)) + 255) / 256, g.ncx * g.ncy), dim3(256), 0, s, d2,
-                       (const float *)mu, h2, (float2 *)nullptr, ctr + 1, g, 1);
+                       (const float *)mu, (const float *)vt, h2, (float2 *)nullptr, ctr + 1, g, 1);
 
     KmGeom a;
     a.g = g; a.LP = p->label_pitch; a.tphi = p->tphi;
@@ -770,7 +794,7 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     sc.h1 = h1; sc.h2 = h2; sc.qs = qs; sc.ev = ev; sc.ev_cnt = ev_cnt;
     size_t shmem = (size_t)KM_NBUF * KM_ABUF;
     hipLaunchKernelGGL(knn_screen_kernel, dim3(g.ncx * g.ncy * wgs_per_cell), dim3(KM_THREADS), shmem, s, a, sc);
-    int rc = dflow_check_launch("knn_screen_kernel");
+    rc = dflow_check_launch("knn_screen_kernel");
     if (rc) return rc;
     KmResolve rs;
     rs.d1 = d1; rs.d2 = d2; rs.ev = ev; rs.ev_cnt = ev_cnt; rs.proposals = proposals; rs.lcosts = lcosts;

@@ -4,9 +4,10 @@
 #include <stddef.h>
 
 #define PCA_SAMPLES 4096
+#define PCA_DELTA_MAX 2e-6      // guaranteed |V^T V - I|_2 of the basis (else the flag is set)
 
 // scratch of the two kernels (partial scatter matrices)
 size_t knn_pca_ws_bytes(void);
-// d2: (npix, 68) float32 descriptors, mu: their centre (68 float32) -> vt: [68 components][68 dimensions] float64, rows
-// sorted by decreasing eigenvalue; sets bit 0 of *flags if the basis is not orthonormal (NaN input)
-int launch_knn_pca(const float *d2, const float *mu, double *vt, int *flags, void *ws, int npix, hipStream_t s);
+// d2: (npix, 68) float32 descriptors, mu: their centre (68 float32) -> vt: [68 components][68 dimensions] float32, rows
+// sorted by decreasing eigenvalue; sets bit 0 of *flags if |V^T V - I|_F > PCA_DELTA_MAX (NaN input)
+int launch_knn_pca(const float *d2, const float *mu, float *vt, int *flags, void *ws, int npix, hipStream_t s);
