@@ -122,12 +122,12 @@ def window_mask(gt, cellh, cellw, window=2):
 
 
 def cpu_baseline(synth, gpu_flow, bench_seed, cellh, cellw):
-    """The CPU oracle (a C port of the reference path) beside the GPU number, on this host's cores.
+    """The CPU oracle (a C port of the reference path) beside the GPU number, on this host's cores; about 15 s in all.
 
-    Entry 1 (headline): the bench's own pair (BASELINE configs[1]: 1024x436, forward, bcd_times=4), all usable cores;
-    its flow is also the EPE reference (`epe_delta_vs_oracle`).  Entry 2: BASELINE configs[0]'s geometry (1241x375,
-    cells 73x25, forward, 1 sweep: daisy i flann.py:34-35,42-43, python bcd.py:261-284) on a synthetic pair, all usable
-    cores.  Entry 3: 1/8 of a Sintel frame single-threaded, the form the reference itself runs in (one core)."""
+    Entry 1 (headline): the bench's own pair (BASELINE configs[1]: 1024x436, forward, bcd_times=4), the box's CPU share;
+    its flow is also the EPE reference (`epe_delta_vs_oracle`).  Entry 2: BASELINE configs[0]'s geometry (cells 73x25 of
+    1241x375, forward, 1 sweep: daisy i flann.py:34-35,42-43, python bcd.py:261-284) on a 5 x 5-cell part of such a frame.
+    Entry 3: 2 x 2 cells of a Sintel frame single-threaded, the form the reference itself runs in (one core)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
@@ -144,20 +144,22 @@ def cpu_baseline(synth, gpu_flow, bench_seed, cellh, cellw):
     oracle_flow = ref["flows"][-1]
     entries.append({"config": "BASELINE configs[1]: the bench pair, 1024x436, cells %dx%d, forward, bcd_times=%d" % (cellw, cellh, BCD_TIMES),
                     "value": H * W / dt / 1e6, "unit": "Mpix/s", "threads": threads, "seconds": dt})
-    kh, kw = 375, 1241
-    a, b, _ = synth.make_pair(kh, kw, seed=synth.pair_seed(6, 0))
+    kh, kw = 125, 365
+    a, b, _ = synth.make_pair(kh, kw, seed=synth.pair_seed(6, 0), amp_x=30.0, amp_y=10.0)
     t0 = time.perf_counter()
     O.full_pass(O.make_params(kh, kw, 25, 73, seed=0), a, b, 1)
     dk = time.perf_counter() - t0
-    entries.append({"config": "BASELINE configs[0] geometry: 1241x375, cells 73x25, idx 6 forward, bcd_times=1 (synthetic pair: KITTI is absent)",
+    entries.append({"config": "BASELINE configs[0] geometry: cells 73x25 (of 1241x375), idx 6 forward, bcd_times=1, on a 365x125 "
+                              "part (5 x 5 cells: every pixel sees the whole window) of a synthetic pair (KITTI is absent)",
                     "value": kh * kw / dk / 1e6, "unit": "Mpix/s", "threads": threads, "seconds": dk})
     O.set_threads(1)
-    sh, sw = 109, 512
-    a, b, _ = synth.make_pair(sh, sw, seed=4242)
+    sh, sw = 54, 128
+    a, b, _ = synth.make_pair(sh, sw, seed=4242, amp_x=12.0, amp_y=6.0)
     t0 = time.perf_counter()
     O.full_pass(O.make_params(sh, sw, 27, 64, seed=1), a, b, BCD_TIMES)
     ds = time.perf_counter() - t0
-    entries.append({"config": "512x109 synthetic pair (1/8 Sintel frame), cells 64x27, bcd_times=%d, single thread like the reference" % BCD_TIMES,
+    entries.append({"config": "128x54 synthetic pair (2 x 2 cells of a Sintel frame: 4 window cells per pixel instead of up to 25), "
+                              "cells 64x27, bcd_times=%d, single thread like the reference" % BCD_TIMES,
                     "value": sh * sw / ds / 1e6, "unit": "Mpix/s", "threads": 1, "seconds": ds})
     base = {"value": entries[0]["value"], "unit": "Mpix/s", "cores": threads, "kind": "port",
             "host_cores": host_cores, "usable_cores": usable,
@@ -520,6 +522,93 @@ def worker(args):
         dist.destroy_process_group()
 
 
+def knn_kernel_times(torch, df, pair, reps=3):
+    """The kernels of the kNN stage one by one, HIP events between them on the launch stream (dflow_knn_proposals_timed),
+    one pair alone on the GPU: ({kernel: mean ms}, MFMA instructions the screen issues)."""
+    st = torch.cuda.Stream(device=df.device)
+    acc, issued = {}, 0.0
+    with torch.cuda.stream(st):
+        df.load_pair(*pair)
+        df.generisi_timed()                               # warm-up
+        for _ in range(reps):
+            ms, issued = df.generisi_timed()
+            for k, v in ms.items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+    st.synchronize()
+    return acc, issued
+
+
+def profile_scalar(name, default=None):
+    """A number from the tracked rocprofv3 PMC summary of this round (profiles/pmc_knn.json), e.g. the clock the chip held."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_knn.json")) as f:
+            return json.load(f).get(name, default)
+    except Exception:
+        return default
+
+
+def other_configs(eng, args):
+    """One-GPU timings of the BASELINE configurations the headline does not cover, so that they are driver-observed:
+    configs[2] (forward + backward pass of one 1024x436 pair + consistency check, postprocessing.py:123-135) and the
+    geometry of configs[4] (1242x375, cells 54x25, fp16 descriptors, bcd_times=8).  Wall clock around synchronised runs."""
+    torch, pl, synth = eng.torch, eng.pipeline, eng.synth
+    _lib = importlib.import_module(PKG + "._lib")
+    dev = eng.dev
+    res = {}
+
+    def run_passes(dfs, jobs, bcd_times, streams):
+        evs = []
+        for j, (df, (a, b)) in enumerate(zip(dfs, jobs)):
+            st = streams[j % len(streams)]
+            with torch.cuda.stream(st):
+                df.load_pair(a, b); df.generisi(); df.nasumicni(); df.pakovanje()
+                e = torch.cuda.Event(); e.record(); evs.append(e)
+        main = torch.cuda.current_stream(dev)
+        for e in evs:
+            main.wait_event(e)
+        pl.ceoBCD_batch(dfs, bcd_times)
+        return [df.vratiKonacniFlow() for df in dfs]
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+        return min(ts), sum(ts) / len(ts)
+
+    streams = eng.front[:2] if hasattr(eng, "front") else [torch.cuda.Stream(device=dev) for _ in range(2)]
+    # configs[2]: both directions of the bench's first pair, then the consistency check
+    dfs = (eng.sets[0][:2] if hasattr(eng, "sets") and len(eng.sets[0]) >= 2 else
+           [pl.DiscreteFlow(H, W, eng.cellh, eng.cellw, device=dev, seed=0) for _ in range(2)])
+    a, b = eng.pairs[0]
+
+    def c2():
+        fwd, bwd = run_passes(dfs, [(a, b), (b, a)], BCD_TIMES, streams)
+        return pl.fb_consistency(fwd, bwd, 10.0, dfs[0].p)
+    best, mean = timed(c2)
+    res["configs[2]"] = {"workload": "forward + backward pass of one 1024x436 pair (bcd_times=%d) + forward/backward consistency check "
+                                     "(threshold 10, README.md:65), 1 GPU: front ends on 2 HIP streams, sweeps of both passes in one "
+                                     "batched launch per phase" % BCD_TIMES,
+                         "ms": best, "ms_mean": mean, "passes": 2, "Mpix/s": 2 * H * W / best / 1e3,
+                         "dtype": "f32 descriptors / f32 distance / f64 DP"}
+    # configs[4] geometry: 4 passes (2 pairs, both directions)
+    kh, kw, kch, kcw, ksweeps = 375, 1242, 25, 54, 8
+    kdfs = [pl.DiscreteFlow(kh, kw, kch, kcw, device=dev, seed=0, flags=_lib.FLAG_DESCR_F16) for _ in range(4)]
+    jobs = []
+    for pr in range(2):
+        i1, i2, _ = synth.make_pair(kh, kw, seed=synth.pair_seed(pr, 0))
+        t1, t2 = torch.from_numpy(i1).to(dev), torch.from_numpy(i2).to(dev)
+        jobs += [(t1, t2), (t2, t1)]
+    best, mean = timed(lambda: run_passes(kdfs, jobs, ksweeps, streams), reps=2)
+    res["configs[4] geometry"] = {"workload": "1242x375, cells 54x25 (discrete_flow.py:22-23,30-31), fp16 DAISY descriptors (DFLOW_FLAG_DESCR_F16), "
+                                              "MFMA-screened exact kNN, bcd_times=8; 2 synthetic pairs x (forward, backward) = 4 passes on 1 GPU "
+                                              "(on 8 GPUs: one pass per rank and step)",
+                                  "ms": best, "ms_mean": mean, "passes": 4, "ms_per_pass": best / 4, "Mpix/s": 4 * kh * kw / best / 1e3,
+                                  "dtype": "f16 descriptors / f32 distance / f64 DP"}
+    del kdfs
+    return res
+
+
 def finish_report(out, eng, args, world):
     torch = eng.torch
     P = eng.P
@@ -532,7 +621,7 @@ def finish_report(out, eng, args, world):
                                      "on rank 0" % (P, args.front)) if args.mode == "batch" else
                                     ("one pass per step; %d independent steps in flight per GPU on separate HIP streams; "
                                      "flow fields gathered on rank 0" % P)}
-    # dominant kernel of a step: bcd_chain_kernel, 4 sweeps x 4 phases = 16 launches between the two events
+    # ---- bcd_chain_kernel: 4 sweeps x 4 phases = 16 launches between the two events of a group
     launches = 4 * BCD_TIMES
     # (start, end, passes in the launch): a batched launch carries the chains of several passes
     bcd_ms = sum(a.elapsed_time(b) for a, b, _ in eng.bcd_events) / max(1, len(eng.bcd_events)) / launches
@@ -544,15 +633,43 @@ def finish_report(out, eng, args, world):
     # the launches of the timed region: column phases (W+1)//2 resp. W//2 chains, row phases (H+1)//2 resp. H//2 chains,
     # 192 threads per chain, times the passes of a group
     traffic, traffic_src = pmc_traffic("bcd_chain_kernel", [((W + 1) // 2) * 192, ((H + 1) // 2) * 192], passes_per_launch)
-    out["roofline"] = {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "traffic": traffic, "traffic_source": traffic_src,
-                       "launch_ms": bcd_ms, "passes_per_launch": passes_per_launch, "algorithmic_bytes_per_launch": alg_bytes,
-                       "launch_ms_per_pass": bcd_ms / passes_per_launch,
-                       "note": "launch_ms = HIP-event time of the 16 chain launches of a group of passes / 16, measured on the "
-                                       "launch stream (%s mode, %d pairs per group / in flight); traffic = rocprofv3 PMC bytes of one "
-                                       "such launch (profiles/)" % (args.mode, P)}
+    chain = {"bound": "hbm", "kernel": "bcd_chain_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "traffic": traffic, "traffic_source": traffic_src,
+             "launch_ms": bcd_ms, "passes_per_launch": passes_per_launch, "algorithmic_bytes_per_launch": alg_bytes,
+             "launch_ms_per_pass": bcd_ms / passes_per_launch, "ms_per_step": bcd_ms * launches / passes_per_launch,
+             "note": "launch_ms = HIP-event time of the 16 chain launches of a group of passes / 16, measured on the "
+                     "launch stream (%s mode, %d pairs per group / in flight); traffic = rocprofv3 PMC bytes of one "
+                     "such launch (profiles/)" % (args.mode, P)}
+    # ---- knn_screen_kernel: one launch per step, timed alone with HIP events on its launch stream
+    knn_ms, mfma_issued = knn_kernel_times(torch, eng.flows[0], eng.pairs[0])
+    screen_ms = knn_ms["knn_screen_kernel"]
+    alg_flops = 2 * 68 * knn_pairs(H, W, eng.cellh, eng.cellw)
+    issued_flops = mfma_issued * 32 * 32 * 16 * 2
+    s_traffic, s_traffic_src = pmc_traffic("knn_screen_kernel")
+    screen = {"bound": "mfma", "kernel": "knn_screen_kernel", "achieved": alg_flops / (screen_ms * 1e-3) / 1e12,
+              "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": alg_flops / (screen_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+              "traffic": s_traffic, "traffic_source": s_traffic_src,
+              "launch_ms": screen_ms, "ms_per_step": screen_ms,
+              "algorithmic_flops_per_launch": alg_flops, "issued_flops_per_launch": issued_flops,
+              "issued_over_algorithmic": issued_flops / alg_flops,
+              "issued_tflops": issued_flops / (screen_ms * 1e-3) / 1e12,
+              "effective_clock_ghz_from_profiles": profile_scalar("knn_screen_kernel_effective_clock_ghz"),
+              "mfma_pipe_busy_frac_from_profiles": profile_scalar("knn_screen_kernel_mfma_busy_frac"),
+              "note": "launch_ms = HIP events around the kernel on its launch stream (dflow_knn_proposals_timed), one pair alone on "
+                      "the GPU, mean of 3; algorithmic flops = 2*68 per (query, candidate) pair of the +-2-cell windows (SURVEY 8(d)); "
+                      "issued = v_mfma_f32_32x32x16_f16 count x 32768 (two passes over the 42 leading principal components "
+                      "+ 6 bound slots, K = 48, padded tiles included)"}
+    dominant = screen if screen["ms_per_step"] >= chain["ms_per_step"] else chain
+    out["roofline"] = dict(dominant)
+    out["roofline"]["dominant_by"] = "ms per step measured in this run: %s %.3f, %s %.3f" % (
+        screen["kernel"], screen["ms_per_step"], chain["kernel"], chain["ms_per_step"])
+    out["roofline"]["kernels"] = {"knn_screen_kernel": screen, "bcd_chain_kernel": chain}
+    out["roofline"]["knn_kernels_ms"] = {k: round(v, 4) for k, v in knn_ms.items()}
     out["roofline"]["stages"] = stage_rooflines(torch, eng.flows[0], eng.pairs[0], eng.cellh, eng.cellw)
+    out["latency_ms_single_pair"] = out["roofline"]["stages"]["ms_total"]
+    out["latency_note"] = ("ms_per_step is pipelined throughput (%d pairs per group, two groups alternating); one pair alone on the GPU, "
+                           "stage after stage on one stream, takes latency_ms_single_pair" % P)
     # flow of the bench's first pair (what the EPE numbers refer to)
     df = eng.flows[0]
     gpu_flow = df.run(eng.pairs[0][0], eng.pairs[0][1], BCD_TIMES).cpu().numpy()
@@ -560,6 +677,8 @@ def finish_report(out, eng, args, world):
     m = window_mask(gt, eng.cellh, eng.cellw)
     out["epe"] = {"gpu": {"all_pixels": epe_stats(gpu_flow, gt), "gt_inside_image_and_search_window": epe_stats(gpu_flow, gt, m)}}
     out["epe_delta_vs_oracle"] = None
+    if world == 1 and not args.no_other_configs:
+        out["other_configs"] = other_configs(eng, args)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"], out["epe"], out["epe_delta_vs_oracle"] = cpu_baseline(eng.synth, gpu_flow, eng.seeds[0], eng.cellh, eng.cellw)
 
@@ -570,6 +689,7 @@ def main():
     ap.add_argument("--steps", type=int, default=96)       # 12 groups of 8: the fill and drain of the two-group pipeline weigh < 10 %
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the one-GPU timings of BASELINE configs[2] and [4]")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent pairs in flight per GPU (each on its own HIP stream and workspace)")
     ap.add_argument("--mode", choices=("streams", "batch"), default="batch",

@@ -89,6 +89,15 @@ int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const floa
                         uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels,
                         void *d_ws, size_t ws_bytes, void *stream);
 
+/* Measurement aid (bench.py's roofline object): the launches of dflow_knn_proposals with HIP events between the kernels on
+ * `stream`.  Same kernels, same results; unlike every other entry point it WAITS for the stream.  h_ms[6] (host) receives the
+ * milliseconds of { basis (centre, covariance, principal axes), prep (both images), knn_screen_kernel, knn_resolve_kernel,
+ * knn_fix_kernel, knn_finalize_kernel }, *h_mfma_issued (host, optional) the number of v_mfma_f32_32x32x16_f16 (32768 flop
+ * each) the screen issues for these parameters.  No reference counterpart. */
+int dflow_knn_proposals_timed(const dflow_params *p, const float *d_descr1, const float *d_descr2,
+                              uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels,
+                              void *d_ws, size_t ws_bytes, void *stream, float *h_ms, double *h_mfma_issued);
+
 /* nasumicni, daisy i flann.py:205-233: appends up to ngauss neighbour proposals per pixel (in place).
  * d_bestlabels must still hold the WTA labels written by dflow_knn_proposals.  Uses 4 bytes per pixel of the workspace
  * (the WTA flow of every pixel, gathered once). */

@@ -95,6 +95,28 @@ int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const floa
     return launch_knn_mfma(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, d_ws, (hipStream_t)stream);
 }
 
+int dflow_knn_proposals_timed(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,
+                              float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream,
+                              float *h_ms, double *h_mfma_issued)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(d_descr1); CHECK_PTR(d_descr2); CHECK_PTR(d_proposals); CHECK_PTR(d_lcosts); CHECK_PTR(d_nprop); CHECK_PTR(d_bestlabels);
+    CHECK_PTR(h_ms);
+    if ((p->flags & DFLOW_FLAG_KNN_EXACT) || !knn_mfma_supported(p))
+        return dflow_set_error(DFLOW_EINVAL, "%s: the MFMA-screened search does not run for these parameters", __func__);
+    CHECK_WS(knn_mfma_ws_bytes(p));
+    hipEvent_t ev[KNN_MFMA_EVENTS];
+    for (int k = 0; k < KNN_MFMA_EVENTS; k++)
+        if (hipEventCreate(&ev[k]) != hipSuccess) return dflow_set_error(DFLOW_EHIP, "hipEventCreate failed");
+    rc = launch_knn_mfma(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, d_ws, (hipStream_t)stream, ev);
+    if (rc == DFLOW_OK && hipEventSynchronize(ev[KNN_MFMA_EVENTS - 1]) != hipSuccess) rc = dflow_set_error(DFLOW_EHIP, "hipEventSynchronize failed");
+    for (int k = 0; rc == DFLOW_OK && k + 1 < KNN_MFMA_EVENTS; k++)
+        if (hipEventElapsedTime(&h_ms[k], ev[k], ev[k + 1]) != hipSuccess) rc = dflow_set_error(DFLOW_EHIP, "hipEventElapsedTime failed");
+    for (int k = 0; k < KNN_MFMA_EVENTS; k++) (void)hipEventDestroy(ev[k]);
+    if (h_mfma_issued) *h_mfma_issued = knn_mfma_issued(p);
+    return rc;
+}
+
 int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,
                               float *d_lcosts, int32_t *d_nprop, const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes,
                               void *stream)

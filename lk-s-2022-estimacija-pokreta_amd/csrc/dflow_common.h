@@ -90,8 +90,10 @@ int launch_daisy(const dflow_params *p, const uint8_t *bgr, float *descr, void *
 size_t daisy_ws_bytes(const dflow_params *p);
 int launch_knn(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
                int32_t *nprop, int32_t *bestlabels, hipStream_t s);
+#define KNN_MFMA_EVENTS 7
 int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
-                    int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s);
+                    int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s, hipEvent_t *ev = nullptr);
+double knn_mfma_issued(const dflow_params *p);
 size_t knn_mfma_ws_bytes(const dflow_params *p);
 bool knn_mfma_supported(const dflow_params *p);
 int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,

@@ -38,8 +38,8 @@
 //
 // MFMA layout (v_mfma_f32_32x32x16_f16): A = candidates (rows), B = queries (columns): lane l holds
 // A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31]; D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5).
-// A workgroup is 8 waves x 64 queries (2 column groups); candidates stream through LDS in chunks of 96 rows (112-byte
-// pitch: conflict-free ds_read_b128) through a ring of 4 buffers filled by global_load_lds DMA.
+// A workgroup is 8 waves x 64 queries (2 column groups); candidates stream through LDS in chunks of 192 rows (112-byte
+// pitch: conflict-free ds_read_b128) through a ring of 3 buffers filled by global_load_lds DMA.
 #include "dflow_common.h"
 #include "knn_pca.h"
 #include "row_stage.h"
@@ -60,12 +60,18 @@ template <int V> struct KmC { static constexpr int value = V; };
 #define KM_THREADS (64 * KM_WAVES)
 #define KM_QPW 64               // queries per wave: 2 column groups of 32
 #define KM_QPB (KM_WAVES * KM_QPW)
-#define KM_CHUNK 96             // candidates per LDS chunk (3 tiles of 32)
+#ifndef KM_CHUNK
+#define KM_CHUNK 192            // candidates per LDS chunk (6 tiles of 32)
+#endif
 #define KM_PITCH 112            // LDS row pitch in bytes (28 dwords: 16 consecutive rows hit 16 distinct 4-bank groups)
 #define KM_SLOTS (KM_PITCH / 16)                  // 16-byte slots per staged row (6 data + 1 pad)
-#define KM_STAGE_INS ((KM_CHUNK * KM_SLOTS + 63) / 64)      // wave-instructions per staged chunk (11, the last one half used)
+#define KM_STAGE_INS ((KM_CHUNK * KM_SLOTS + 63) / 64)      // wave-instructions per staged chunk (21)
 #define KM_ABUF (KM_STAGE_INS * 1024)            // bytes per staged chunk buffer
-#define KM_NBUF 4                // ring of staged chunks: the DMA runs 3 chunks ahead of the MFMAs
+#ifndef KM_NBUF
+#define KM_NBUF 3                // ring of staged chunks: the DMA runs KM_NBUF - 1 chunks ahead of the MFMAs
+#endif
+#define KM_MAXNW ((KM_STAGE_INS + KM_WAVES - 1) / KM_WAVES)     // DMA instructions of a wave per chunk: KM_MAXNW or one fewer
+#define KM_SPC (2 * (KM_CHUNK / 32))                           // event stores of a wave per chunk in pass 2 (tiles x groups)
 #define KM_EVROWS 32            // event entries (tile, 16-bit row mask) per lane, group and candidate cell
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
 #define KM_LIST_WORDS (2 * KM_EVROWS * 64)       // one event list: [group][entry][lane] uint32
@@ -89,7 +95,7 @@ __device__ static inline size_t list_id(const KmGeom &a, int qcell, int qwave, i
 // ------------------------------------------------------------------------------------------------ prep
 // Candidate (image 2) rows are stored cell by cell in TILE POSITION order, every cell padded to whole chunks: position
 // (tile, row) of cell c holds candidate row * ntiles + tile of that cell (see the screen kernel), positions without a
-// candidate hold the sentinel row.  The screen then stages a chunk as one contiguous 9 KB read.
+// candidate hold the sentinel row.  The screen then stages a chunk as one contiguous 18 KB read.
 __host__ __device__ static inline int km_pad(int npts) { return (npts + KM_CHUNK - 1) / KM_CHUNK * KM_CHUNK; }
 __host__ __device__ static inline size_t km_cell_base(const Geom &g, int ci, int cj)
 {
@@ -323,15 +329,15 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     const int nchunks = (cnpts + KM_CHUNK - 1) / KM_CHUNK;
     const size_t cbase = km_cell_base(g, ci, cj);
     // Asynchronous staging of one chunk straight into LDS (global_load_lds_dwordx4: the LDS address is wave-uniform
-    // base + 16*lane, the global address is per lane).  The LDS image is 96 rows of 7 16-byte slots (6 data + 1
-    // pad = 112-byte pitch) = 672 slots = 11 wave-instructions (the last one half used; the buffer is 11 KB).
+    // base + 16*lane, the global address is per lane).  The LDS image is 192 rows of 7 16-byte slots (6 data + 1
+    // pad = 112-byte pitch) = 1344 slots = 21 wave-instructions (the buffer is 21 KB; 3 of them per workgroup).
     // Pad slots re-read part 0; positions beyond the cell hold sentinel rows (MFMA value -60000 < every real one).
     // the byte offsets of this wave's (at most two) DMA instructions inside a chunk do not depend on the chunk: computed
     // once; per chunk only the scalar base moves (scalar base + 32-bit lane offset addressing)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    uint32_t soff[2];
+    uint32_t soff[KM_MAXNW];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < KM_MAXNW; i++) {
         const int slot = (wave_u + i * KM_WAVES) * 64 + lane;
         // the candidate rows are stored in tile position order (knn_prep_kernel): position p = (tile, row) holds
         // candidate row * ntiles + tile, so that the 16 rows a lane sees of one tile are far apart in the cell.
@@ -346,34 +352,38 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     auto stage = [&](int chunk, int buf) {
         char *base = abuf + (size_t)buf * KM_ABUF + wave_u * 1024;
         const rs_gptr src = h2cell + (size_t)min(chunk, nchunks - 1) * (KM_CHUNK * KM_K * 2);   // chunks staged past the end (never used) re-read the last one
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + soff[0]),
-                                         (__attribute__((address_space(3))) void *)base, 16, 0, 0);
-        if (n_w == 2)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + soff[1]),
-                                             (__attribute__((address_space(3))) void *)(base + KM_WAVES * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < KM_MAXNW; i++)
+            if (i < KM_MAXNW - 1 || n_w == KM_MAXNW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + soff[i]),
+                                                 (__attribute__((address_space(3))) void *)(base + i * KM_WAVES * 1024), 16, 0, 0);
     };
 
     float a5[2][5];
     int cnt[2] = {0, 0};
     const uint32_t evoff[2] = {(uint32_t)lane * 4u, (uint32_t)lane * 4u + KM_EVROWS * 256u};
     const size_t lid = list_id(a, qcell, qwave, wslot);
-    const rs_gptr evlist = (rs_gptr)(p.ev + lid * KM_LIST_WORDS);       // wave-uniform; entry (gq, row) of a lane at 4 lane + 256 (32 gq + row)
+    // wave-uniform buffer resource over this list; entry (gq, row) of a lane at 4 lane + 256 (32 gq + row)
+    const __amdgpu_buffer_rsrc_t evrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ev + lid * KM_LIST_WORDS), 0, KM_LIST_WORDS * 4, 0x00020000);
 
 #pragma unroll
     for (int gq = 0; gq < 2; gq++)
 #pragma unroll
         for (int i = 0; i < 5; i++) a5[gq][i] = -INFINITY;
 
-    // A wave issues n_w (2 for waves 0..2, else 1) DMA instructions per chunk, and in pass 2 exactly 6 event stores (one per tile and
-    // column group, unconditionally: empty masks go to a scratch row).  Before the barrier that publishes chunk c+1 it
-    // waits until only the DMAs of chunks c+2 and c+3 and the stores of chunks c-1 and c may still be in flight
-    // (vmcnt counts all of them in issue order).  Chunks and tiles past the end of the cell are still staged/processed
+    // A wave issues n_w (KM_MAXNW or one fewer) DMA instructions per chunk, and in pass 2 exactly KM_SPC event stores (one per
+    // tile and column group, unconditionally).  Before the barrier that publishes chunk c+1 it waits until only the DMAs of
+    // chunks c+2 .. c+KM_NBUF-1 and the stores of chunks c-1 and c may still be in flight (vmcnt counts all of them in
+    // issue order).  Chunks and tiles past the end of the cell are still staged/processed
     // (sentinel rows) so that these counts are exact.
+    // (counted waits need immediates: one instantiation per count)
     auto wait_ring = [&](int pass) {
         if (pass == 0) {
-            if (n_w == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (n_w == KM_MAXNW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KM_NBUF - 2) * KM_MAXNW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KM_NBUF - 2) * (KM_MAXNW - 1)) : "memory");
         } else {
-            if (n_w == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            if (n_w == KM_MAXNW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KM_NBUF - 2) * KM_MAXNW + 2 * KM_SPC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KM_NBUF - 2) * (KM_MAXNW - 1) + 2 * KM_SPC) : "memory");
         }
         __builtin_amdgcn_s_barrier();
     };
@@ -386,14 +396,14 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         uint32_t neg = 0u;
 #pragma unroll
         for (int r = 15; r >= 0; r--) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(acc[r]), 31);
-        // entry = (tile << 16) | (~neg & 0xFFFF) = neg ^ ((tile << 16) | 0xFFFF).  Always one store (the vmcnt bookkeeping of
-        // the ring counts on it), to entry cnt of the lane's list; cnt only advances past entries with a mask, so an
-        // empty one is overwritten by the next (same lane, same address: in order) or stays behind the end of the list.
+        // entry = (tile << 16) | (~neg & 0xFFFF) = neg ^ ((tile << 16) | 0xFFFF).  Always one store instruction (the vmcnt
+        // bookkeeping of the ring counts on it): lanes with a mask write entry cnt of their list, the others (95 %) an offset
+        // beyond the buffer's range, which the hardware drops without any memory traffic (raw buffer store, range checked).
         // Entry KM_EVROWS-1 is never valid: a list that reaches it is reported as overflowed.
-        const uint32_t off = evoff[gq] + ((uint32_t)min(cnt[gq], KM_EVROWS - 1) << 8);
-        *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(const_cast<__attribute__((address_space(1))) char *>(evlist) + off) =
-            neg ^ (((uint32_t)tileidx << 16) | 0xFFFFu);
-        cnt[gq] += neg != 0xFFFFu ? 1 : 0;
+        const bool has = neg != 0xFFFFu;
+        const uint32_t off = has ? evoff[gq] + ((uint32_t)min(cnt[gq], KM_EVROWS - 1) << 8) : 0xFFFFFF00u;
+        __builtin_amdgcn_raw_buffer_store_b32(neg ^ (((uint32_t)tileidx << 16) | 0xFFFFu), evrsrc, (int)off, 0, 0);
+        cnt[gq] += has ? 1 : 0;
     };
     // the pipeline starts with a harmless unit: -inf never enters a top-5 (pass 1) and is negative (pass 2)
     const f32x16 minus_inf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY,
@@ -401,57 +411,70 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     // the tiles of one staged chunk; PASS is a compile-time constant (the scheduling directives need constants)
     f32x16 pend;
     int pend_tile = 0;
-    auto tiles = [&](auto passc, const int chunk, const char *ab) __attribute__((always_inline)) {
+    // one tile: af = its A fragments (already in registers), afn <- those of the next tile of the chunk (if any), fetched
+    // while the MFMAs of this tile run, so that only the first tile of a chunk waits for LDS
+    auto one_tile = [&](auto passc, const int tileidx, const half8 (&af)[KM_KSTEPS], half8 (&afn)[KM_KSTEPS], const char *arow_next) __attribute__((always_inline)) {
         constexpr int PASS = decltype(passc)::value;
-#pragma unroll 1
-        for (int tile = 0; tile < KM_CHUNK / 32; tile++) {
-            const int tileidx = chunk * (KM_CHUNK / 32) + tile;
-            half8 af[KM_KSTEPS];
-            const char *arow = ab + (tile * 32 + col) * KM_PITCH + half * 16;
+        if (arow_next) {
 #pragma unroll
-            for (int s = 0; s < KM_KSTEPS; s++) af[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
-            __builtin_amdgcn_sched_barrier(0);
-            // unit (tile, group 0): its three MFMAs (one dependent chain, 32 cycles each) with the pending epilogue of
-            // (previous tile, group 1) issued in their shadow, a few VALU per MFMA: the scheduler is told to build that
-            // pipeline (sched_group_barrier) and not to mix the two halves (sched_barrier), otherwise it clusters the
-            // MFMAs of both groups and the epilogues behind them, and the waves of a SIMD then alternate in lockstep
-            // between matrix-only and vector-only phases (matrix pipe 55 % busy)
-            f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KM_KSTEPS; s++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[0][s], acc0, 0, 0, 0);
-            if (PASS == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile);
-#pragma unroll
-            for (int s = 0; s < KM_KSTEPS; s++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 5 : 7, 0);   // VALU of the epilogue in its shadow
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // unit (tile, group 1): MFMAs, in their shadow the epilogue of (tile, group 0)
-            f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KM_KSTEPS; s++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[1][s], acc1, 0, 0, 0);
-            if (PASS == 0) epi1(acc0, 0); else epi2(acc0, 0, tileidx);
-#pragma unroll
-            for (int s = 0; s < KM_KSTEPS; s++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 5 : 7, 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            pend = acc1; pend_tile = tileidx;
+            for (int s = 0; s < KM_KSTEPS; s++) afn[s] = *reinterpret_cast<const half8 *>(arow_next + s * 32);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // unit (tile, group 0): its three MFMAs (one dependent chain, 32 cycles each) with the pending epilogue of
+        // (previous tile, group 1) issued in their shadow, a few VALU per MFMA: the scheduler is told to build that
+        // pipeline (sched_group_barrier) and not to mix the two halves (sched_barrier), otherwise it clusters the
+        // MFMAs of both groups and the epilogues behind them, and the waves of a SIMD then alternate in lockstep
+        // between matrix-only and vector-only phases
+        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KM_KSTEPS; s++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[0][s], acc0, 0, 0, 0);
+        if (PASS == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile);
+#pragma unroll
+        for (int s = 0; s < KM_KSTEPS; s++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 5 : 8, 0);   // VALU of the epilogue in its shadow
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // unit (tile, group 1): MFMAs, in their shadow the epilogue of (tile, group 0)
+        f32x16 acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KM_KSTEPS; s++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bfrag[1][s], acc1, 0, 0, 0);
+        if (PASS == 0) epi1(acc0, 0); else epi2(acc0, 0, tileidx);
+#pragma unroll
+        for (int s = 0; s < KM_KSTEPS; s++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x002, PASS == 0 ? 5 : 8, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pend = acc1; pend_tile = tileidx;
+    };
+    auto tiles = [&](auto passc, const int chunk, const char *ab) __attribute__((always_inline)) {
+        static_assert((KM_CHUNK / 32) % 2 == 1 || KM_CHUNK / 32 >= 2, "tiles per chunk");
+        half8 afa[KM_KSTEPS], afb[KM_KSTEPS];
+        const char *arow = ab + col * KM_PITCH + half * 16;
+#pragma unroll
+        for (int s = 0; s < KM_KSTEPS; s++) afa[s] = *reinterpret_cast<const half8 *>(arow + s * 32);
+        const int tile0 = chunk * (KM_CHUNK / 32);
+#pragma unroll 1
+        for (int tile = 0; tile + 1 < KM_CHUNK / 32; tile += 2) {
+            one_tile(passc, tile0 + tile, afa, afb, arow + (tile + 1) * 32 * KM_PITCH);
+            one_tile(passc, tile0 + tile + 1, afb, afa, tile + 2 < KM_CHUNK / 32 ? arow + (tile + 2) * 32 * KM_PITCH : nullptr);
+        }
+        if ((KM_CHUNK / 32) % 2 == 1) one_tile(passc, tile0 + KM_CHUNK / 32 - 1, afa, afb, nullptr);
     };
     for (int pass = 0; pass < 2; pass++) {
-        stage(0, 0); stage(1, 1); stage(2, 2);
-        if (n_w == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < KM_NBUF - 1; c++) stage(c, c);
+        if (n_w == KM_MAXNW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KM_NBUF - 2) * KM_MAXNW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KM_NBUF - 2) * (KM_MAXNW - 1)) : "memory");
         __builtin_amdgcn_s_barrier();
         // Software pipeline: the epilogue of the previous (tile, group) unit is issued behind the MFMAs of the current
         // one, so the VALU work runs while the matrix pipe is busy.  The pipeline starts with a harmless unit (-inf).
         pend = minus_inf;
         pend_tile = 0;
         for (int chunk = 0; chunk < nchunks; chunk++) {
-            const int buf = chunk & (KM_NBUF - 1);
-            stage(chunk + 3, (chunk + 3) & (KM_NBUF - 1));                // that buffer was released by the previous barrier
+            const int buf = chunk % KM_NBUF;
+            stage(chunk + KM_NBUF - 1, (chunk + KM_NBUF - 1) % KM_NBUF);                // that buffer was released by the previous barrier
             const char *ab = abuf + (size_t)buf * KM_ABUF;
             if (wave_active) { if (pass == 0) tiles(KmC<0>(), chunk, ab); else tiles(KmC<1>(), chunk, ab); }
             wait_ring(pass);
@@ -755,9 +778,11 @@ bool knn_mfma_supported(const dflow_params *p)
 int launch_knn_fix(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
                    const int *ovf_count, const int4 *ovf_list, int ovf_cap, const int *flags, hipStream_t s);
 
+// ev (optional, profiling): KNN_MFMA_EVENTS events recorded on s at the boundaries basis | prep | screen | resolve | fix | finalize
 int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
-                    int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s)
+                    int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s, hipEvent_t *tev)
 {
+    auto mark = [&](int k) { if (tev) (void)hipEventRecord(tev[k], s); };
     Geom g = make_geom(p);
     size_t N = (size_t)g.H * g.W, nl = num_lists(p);
     auto align256 = [](char *w) { return (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255); };
@@ -778,13 +803,16 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     if (hipMemsetAsync(ctr, 0, 256, s) != hipSuccess)
         return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_knn_mfma");
     int nb = (int)((N + 255) / 256);
+    mark(0);
     hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(1024), 0, s, d2, mu, (int)N);
     int rc = launch_knn_pca(d2, mu, vt, ctr + 1, pca_ws, (int)N, s);
     if (rc) return rc;
+    mark(1);
     hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, (const float *)mu, (const float *)vt, h1, qs, ctr + 1, g, 0);
     hipLaunchKernelGGL(knn_prep_kernel, dim3((km_pad(max_cell_points(g)) + 255) / 256, g.ncx * g.ncy), dim3(256), 0, s, d2,
                        (const float *)mu, (const float *)vt, h2, (float2 *)nullptr, ctr + 1, g, 1);
 
+    mark(2);
     KmGeom a;
     a.g = g; a.LP = p->label_pitch; a.tphi = p->tphi;
     a.qwaves = (max_cell_points(g) + KM_QPW - 1) / KM_QPW;
@@ -796,14 +824,38 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     hipLaunchKernelGGL(knn_screen_kernel, dim3(g.ncx * g.ncy * wgs_per_cell), dim3(KM_THREADS), shmem, s, a, sc);
     rc = dflow_check_launch("knn_screen_kernel");
     if (rc) return rc;
+    mark(3);
     KmResolve rs;
     rs.d1 = d1; rs.d2 = d2; rs.ev = ev; rs.ev_cnt = ev_cnt; rs.proposals = proposals; rs.lcosts = lcosts;
     rs.ovf_count = ctr; rs.ovf_list = ovf; rs.ovf_cap = KM_OVF_CAP;
     hipLaunchKernelGGL(knn_resolve_kernel, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
     rc = dflow_check_launch("knn_resolve_kernel");
     if (rc) return rc;
+    mark(4);
     rc = launch_knn_fix(p, d1, d2, proposals, lcosts, ctr, ovf, KM_OVF_CAP, ctr + 1, s);
     if (rc) return rc;
+    mark(5);
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)((N * 16 + 255) / 256)), dim3(256), 0, s, g, a.LP, proposals, lcosts, nprop, bestlabels);
+    mark(6);
     return dflow_check_launch("knn_finalize_kernel");
+}
+
+// MFMA instructions the screen issues for these parameters (2 passes x KM_KSTEPS per 32 x 32 tile of padded cells), for
+// bench.py's "issued flops": each is 32 x 32 x 16 x 2 flop
+double knn_mfma_issued(const dflow_params *p)
+{
+    Geom g = make_geom(p);
+    double n = 0.0;
+    for (int qcj = 0; qcj < g.ncy; qcj++)
+        for (int qci = 0; qci < g.ncx; qci++) {
+            const int qnpts = (g.x1(qci) - g.x0(qci)) * (g.y1(qcj) - g.y0(qcj));
+            const int qgroups = 2 * ((qnpts + KM_QPW - 1) / KM_QPW);               // 32-query column groups incl. padding
+            for (int ci = qci - g.win; ci <= qci + g.win; ci++)
+                for (int cj = qcj - g.win; cj <= qcj + g.win; cj++) {
+                    if (ci < 0 || ci >= g.ncx || cj < 0 || cj >= g.ncy) continue;
+                    const int cnpts = (g.x1(ci) - g.x0(ci)) * (g.y1(cj) - g.y0(cj));
+                    n += (double)qgroups * (km_pad(cnpts) / 32) * 2.0 * KM_KSTEPS;
+                }
+        }
+    return n;
 }

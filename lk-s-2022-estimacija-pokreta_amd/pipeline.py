@@ -100,6 +100,20 @@ class DiscreteFlow:
                                                   self.ws.data_ptr(), self.ws_bytes, self._stream()),
                    "dflow_knn_proposals")
 
+    KNN_KERNELS = ("basis", "prep", "knn_screen_kernel", "knn_resolve_kernel", "knn_fix_kernel", "knn_finalize_kernel")
+
+    def generisi_timed(self):
+        """generisi with HIP events between its kernels (dflow_knn_proposals_timed): returns ({kernel: ms}, MFMAs issued)."""
+        self._bcd_ready = False
+        ms = (C.c_float * 6)()
+        issued = C.c_double()
+        _lib.check(_lib.lib().dflow_knn_proposals_timed(self._pp(), self.descrs1.data_ptr(), self.descrs2.data_ptr(),
+                                                        self.proposals.data_ptr(), self.lcosts.data_ptr(),
+                                                        self.nprop.data_ptr(), self.bestlabels.data_ptr(),
+                                                        self.ws.data_ptr(), self.ws_bytes, self._stream(), ms, C.byref(issued)),
+                   "dflow_knn_proposals_timed")
+        return dict(zip(self.KNN_KERNELS, (float(v) for v in ms))), float(issued.value)
+
     def nasumicni(self):
         """daisy i flann.py:205-233."""
         self._bcd_ready = False

@@ -11,7 +11,7 @@ df = pl.DiscreteFlow(H, W, seed=99)
 df.load_pair(img1, img2); df.generisi(); torch.cuda.synchronize()
 N = H * W
 def al(x): return (x + 255) // 256 * 256
-rows2 = 15 * 16 * 1728 + 16 * 2016
+rows2 = 15 * 16 * 1728 + 16 * 2112          # cells padded to whole chunks of 192 rows
 base = df.ws.data_ptr()
 off = (N + rows2) * KM_K * 2 + N * 8
 off = al(base + off) - base
