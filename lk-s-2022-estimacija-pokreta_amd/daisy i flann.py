@@ -6,8 +6,11 @@
 Same positional arguments, same image naming (../data_scene_flow/training/image_2/0001{idx}_1{0|1}.png), same
 output files in the current directory: the WTA flow/labels "posle 00", proposals_nakon_gausa,
 lcosts_nakon_gausa, nprop -- in the reference's dtypes -- plus a Middlebury .flo next to every flow .npy.
-The compat bit matrices (packedksets, 2.6 GB; with dopython=0 the four 'pakovani za c' copies) are written only with
---packedksets, for users of the reference's own BCD scripts: the GPU BCD builds its own compact lists in HBM.
+The compat bit matrices (packedksets; with dopython=0 the four 'pakovani za c' copies) exist for users of the reference's own
+BCD scripts (its `python bcd.py:76` cannot start without packedksets.npy); the GPU BCD of this package builds its own compact
+lists in HBM and never reads them.  They are written by default while the file stays below PACKEDKSETS_DEFAULT_LIMIT bytes
+(256 MiB: frames up to about 47 000 pixels); for larger frames (KITTI: 2.6 GB) one line says so and names the flag,
+--packedksets writes them regardless of size, --no-packedksets never.
 All computation runs in libdflow.so on the GPU; there is no CPU fallback.
 
 Options for inputs the reference cannot handle: --image1/--image2 PATH, --cell HxW, --synthetic HxW
@@ -25,6 +28,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.basename(os.path.dirname(os.path.abspath(__file__)))
 
 
+PACKEDKSETS_DEFAULT_LIMIT = 256 << 20
+
+
 def read_bgr(path):
     from PIL import Image
     return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[..., ::-1])
@@ -35,7 +41,8 @@ def main(argv=None):
     ap.add_argument("picindex"); ap.add_argument("backward", choices=("0", "1")); ap.add_argument("dopython", choices=("0", "1"))
     ap.add_argument("--image1"); ap.add_argument("--image2"); ap.add_argument("--cell"); ap.add_argument("--synthetic")
     ap.add_argument("--seed", type=int, default=0); ap.add_argument("--device", default="cuda:0")
-    ap.add_argument("--packedksets", action="store_true", help="also write the reference's compat-matrix file(s)")
+    ap.add_argument("--packedksets", action="store_true", help="write the reference's compat-matrix file(s) whatever their size")
+    ap.add_argument("--no-packedksets", action="store_true", help="never write them")
     ap.add_argument("--fp16-descriptors", action="store_true", help="round the DAISY values to binary16 (DFLOW_FLAG_DESCR_F16)")
     a = ap.parse_args(argv)
     pipeline = importlib.import_module(PKG + ".pipeline")
@@ -70,7 +77,11 @@ def main(argv=None):
     np.save(flowio.stage_name(idx, a.backward, "proposals_nakon_gausa"), st["proposals"])   # sacuvajPodatke1 :249-253
     np.save(flowio.stage_name(idx, a.backward, "lcosts_nakon_gausa"), st["lcosts"])
     np.save(flowio.stage_name(idx, a.backward, "nprop"), st["nprop"])
-    if a.packedksets:                                                       # pakovanje :308 / pakovanjeZaC :394-397
+    pk_bytes = pich * picw * 2 * (df.p.maxnprop * df.p.maxnprop // 8 + 1)
+    if not a.packedksets and not a.no_packedksets and pk_bytes > PACKEDKSETS_DEFAULT_LIMIT:
+        print("daisy i flann: packedksets (%.2f GB) not written: this package's `python bcd.py` builds its own lists on the GPU; "
+              "pass --packedksets if the reference's own `python bcd.py` is to read these files" % (pk_bytes / 1e9))
+    if a.packedksets or (not a.no_packedksets and pk_bytes <= PACKEDKSETS_DEFAULT_LIMIT):   # pakovanje :308 / pakovanjeZaC :394-397
         compat = importlib.import_module(PKG + ".compat")
         pk = compat.packedksets(df)
         if a.dopython == "1":

@@ -543,7 +543,8 @@ def test_cli_end_to_end(torch_, oracle, synth, tmp_path, monkeypatch):
     O = oracle
     H, W, ch, cw = 48, 64, 8, 8
     monkeypatch.chdir(tmp_path)
-    monkeypatch.setattr(sys, "argv", ["daisy i flann.py", "6", "0", "1", "--synthetic", "%dx%d" % (H, W), "--cell", "%dx%d" % (ch, cw), "--seed", "11", "--packedksets"])
+    # no --packedksets: like the reference (daisy i flann.py:308,430) the default writes the file (this frame is far below the size limit)
+    monkeypatch.setattr(sys, "argv", ["daisy i flann.py", "6", "0", "1", "--synthetic", "%dx%d" % (H, W), "--cell", "%dx%d" % (ch, cw), "--seed", "11"])
     runpy.run_path(os.path.join(ROOT, PKG, "daisy i flann.py"), run_name="__main__")
     monkeypatch.setattr(sys, "argv", ["python bcd.py", "6", "0", "2", "--cell", "%dx%d" % (ch, cw)])
     runpy.run_path(os.path.join(ROOT, PKG, "python bcd.py"), run_name="__main__")
