@@ -16,6 +16,7 @@
  * Device layouts (H = pich, W = picw, LP = label_pitch >= maxnprop, multiple of 16)
  *   image      uint8   (H,W,3)   BGR, as cv2.imread returns it            daisy i flann.py:26-27,52-53
  *   descr      float32 (H,W,68)  row y*W+x = keypoint order               daisy i flann.py:69-77
+ *              or, with DFLOW_FLAG_DESCR_F16, binary16 (H,W,72): 68 values + 4 zero pads per pixel (144-byte rows)
  *   proposals  uint32  (H,W,LP)  one label = int16 dy | int16 dx << 16,   daisy i flann.py:89 (int64 (H,W,150,2), -1 fill)
  *                                unused slots 0xFFFFFFFF (= [-1,-1])
  *   lcosts     float32 (H,W,LP)  unused slots 1000.0f                     daisy i flann.py:90 (float64; values are float32-exact)
@@ -42,9 +43,12 @@ extern "C" {
 #define DFLOW_FLAG_KNN_EXACT 1   /* dflow_knn_proposals: brute-force VALU search instead of the MFMA-screened one (same
                                     results bit for bit; the cross-check of the screen's error bound) */
 
-#define DFLOW_FLAG_DESCR_F16 8    /* dflow_daisy: descriptor values rounded to IEEE binary16 (round to nearest even) before they are
-                                    stored (as float32): BASELINE configs[4] "fp16 DAISY descriptors".  Everything downstream (exact
-                                    kNN, costs, BCD) then works on those values; the reference has no such mode (cv2 returns f32) */
+#define DFLOW_FLAG_DESCR_F16 8    /* BASELINE configs[4] "fp16 DAISY descriptors": dflow_daisy rounds the descriptor values to IEEE
+                                    binary16 (round to nearest even) and stores them as binary16, (H,W,72) with 4 zero pads per
+                                    pixel; dflow_knn_proposals / dflow_neighbour_proposals called with the flag read that layout.
+                                    All arithmetic downstream (canonical float32 distance, costs, BCD) is on those values widened to
+                                    float32; the reference has no such mode (cv2 returns float32) */
+#define DFLOW_DESC_PITCH_F16 72  /* elements per pixel of a binary16 descriptor plane */
 
 #define DFLOW_OK 0
 #define DFLOW_EINVAL (-1)        /* bad parameter / null pointer / unsupported geometry */
@@ -79,13 +83,13 @@ void dflow_default_params(dflow_params *p, int32_t pich, int32_t picw, int32_t c
 size_t dflow_workspace_bytes(const dflow_params *p);
 
 /* izracunajDaisy, daisy i flann.py:69-77 (cv2.xfeatures2d.DAISY_create(radius=5,q_radius=4,q_theta=4,q_hist=4)
- * .compute on every pixel).  d_bgr (H,W,3) uint8 -> d_descr (H,W,68) float32. */
-int dflow_daisy(const dflow_params *p, const uint8_t *d_bgr, float *d_descr,
+ * .compute on every pixel).  d_bgr (H,W,3) uint8 -> d_descr (H,W,68) float32 (binary16 (H,W,72) with DFLOW_FLAG_DESCR_F16). */
+int dflow_daisy(const dflow_params *p, const uint8_t *d_bgr, void *d_descr,
                 void *d_ws, size_t ws_bytes, void *stream);
 
 /* napraviCD2 + generisi, daisy i flann.py:144-189: per-cell exact 5-NN proposals, truncated-L1 costs,
  * WTA labels.  Initialises and fills proposals/lcosts/nprop/bestlabels. */
-int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2,
+int dflow_knn_proposals(const dflow_params *p, const void *d_descr1, const void *d_descr2,
                         uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels,
                         void *d_ws, size_t ws_bytes, void *stream);
 
@@ -94,14 +98,14 @@ int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const floa
  * milliseconds of { basis (centre, covariance, principal axes), prep (both images), knn_screen_kernel, knn_resolve_kernel,
  * knn_fix_kernel, knn_finalize_kernel }, *h_mfma_issued (host, optional) the number of v_mfma_f32_32x32x16_f16 (32768 flop
  * each) the screen issues for these parameters.  No reference counterpart. */
-int dflow_knn_proposals_timed(const dflow_params *p, const float *d_descr1, const float *d_descr2,
+int dflow_knn_proposals_timed(const dflow_params *p, const void *d_descr1, const void *d_descr2,
                               uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels,
                               void *d_ws, size_t ws_bytes, void *stream, float *h_ms, double *h_mfma_issued);
 
 /* nasumicni, daisy i flann.py:205-233: appends up to ngauss neighbour proposals per pixel (in place).
  * d_bestlabels must still hold the WTA labels written by dflow_knn_proposals.  Uses 4 bytes per pixel of the workspace
  * (the WTA flow of every pixel, gathered once). */
-int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2,
+int dflow_neighbour_proposals(const dflow_params *p, const void *d_descr1, const void *d_descr2,
                               uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop,
                               const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream);
 

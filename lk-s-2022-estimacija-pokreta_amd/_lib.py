@@ -16,6 +16,7 @@ SYMBOLS = ("dflow_version", "dflow_last_error", "dflow_default_params", "dflow_w
 
 FLAG_KNN_EXACT = 1      # DFLOW_FLAG_KNN_EXACT
 FLAG_DESCR_F16 = 8      # DFLOW_FLAG_DESCR_F16
+DESC_PITCH_F16 = 72     # DFLOW_DESC_PITCH_F16: binary16 descriptor planes are (H,W,72)
 
 
 class DflowError(RuntimeError):

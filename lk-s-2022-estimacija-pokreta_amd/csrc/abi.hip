@@ -76,14 +76,14 @@ size_t dflow_workspace_bytes(const dflow_params *p)
 #define CHECK_WS(need) do { if (!d_ws || ws_bytes < (need)) \
     return dflow_set_error(DFLOW_ENOSPC, "%s: workspace %zu < %zu bytes", __func__, ws_bytes, (size_t)(need)); } while (0)
 
-int dflow_daisy(const dflow_params *p, const uint8_t *d_bgr, float *d_descr, void *d_ws, size_t ws_bytes, void *stream)
+int dflow_daisy(const dflow_params *p, const uint8_t *d_bgr, void *d_descr, void *d_ws, size_t ws_bytes, void *stream)
 {
     int rc = dflow_check_params(p); if (rc) return rc;
     CHECK_PTR(d_bgr); CHECK_PTR(d_descr); CHECK_WS(daisy_ws_bytes(p));
     return launch_daisy(p, d_bgr, d_descr, d_ws, (hipStream_t)stream);
 }
 
-int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,
+int dflow_knn_proposals(const dflow_params *p, const void *d_descr1, const void *d_descr2, uint32_t *d_proposals,
                         float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream)
 {
     int rc = dflow_check_params(p); if (rc) return rc;
@@ -95,7 +95,7 @@ int dflow_knn_proposals(const dflow_params *p, const float *d_descr1, const floa
     return launch_knn_mfma(p, d_descr1, d_descr2, d_proposals, d_lcosts, d_nprop, d_bestlabels, d_ws, (hipStream_t)stream);
 }
 
-int dflow_knn_proposals_timed(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,
+int dflow_knn_proposals_timed(const dflow_params *p, const void *d_descr1, const void *d_descr2, uint32_t *d_proposals,
                               float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels, void *d_ws, size_t ws_bytes, void *stream,
                               float *h_ms, double *h_mfma_issued)
 {
@@ -117,7 +117,7 @@ int dflow_knn_proposals_timed(const dflow_params *p, const float *d_descr1, cons
     return rc;
 }
 
-int dflow_neighbour_proposals(const dflow_params *p, const float *d_descr1, const float *d_descr2, uint32_t *d_proposals,
+int dflow_neighbour_proposals(const dflow_params *p, const void *d_descr1, const void *d_descr2, uint32_t *d_proposals,
                               float *d_lcosts, int32_t *d_nprop, const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes,
                               void *stream)
 {

@@ -146,10 +146,16 @@ __global__ void gather_kernel(const float4 *__restrict__ cubes, float4 *__restri
         out = tadd(out, tmul<float4>(w2, B));
         out = tadd(out, tmul<float4>(w3, D));
     }
-    if (f16) {   // DFLOW_FLAG_DESCR_F16: descriptor values rounded to binary16 (round to nearest even), kept in float32 storage
-        out.x = (float)(_Float16)out.x; out.y = (float)(_Float16)out.y; out.z = (float)(_Float16)out.z; out.w = (float)(_Float16)out.w;
+    if (f16) {
+        // DFLOW_FLAG_DESCR_F16: descriptor values rounded to binary16 (round to nearest even) and STORED as binary16: rows of
+        // 68 values + 4 zero pads = 144 bytes (the last region's thread writes the pad)
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 *row = reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(descr) + pix * DFLOW_DESC_PITCH_H);
+        row[region] = (h4){(_Float16)out.x, (_Float16)out.y, (_Float16)out.z, (_Float16)out.w};
+        if (region == 16) row[17] = (h4){(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    } else {
+        descr[gid] = out;
     }
-    descr[gid] = out;
 }
 
 // ---- host side: filter taps exactly as the oracle computes them (same libm, same expressions)
@@ -183,7 +189,7 @@ size_t daisy_ws_bytes(const dflow_params *p)
     return N * sizeof(float) * (1 + 1 + 4 + 4 + 16);   // img, sm, tmp(float4), lay(float4), 4 cubes(float4)
 }
 
-int launch_daisy(const dflow_params *p, const uint8_t *bgr, float *descr, void *ws, hipStream_t s)
+int launch_daisy(const dflow_params *p, const uint8_t *bgr, void *descr, void *ws, hipStream_t s)
 {
     const double pi = 3.14159265358979323846;
     int H = p->pich, W = p->picw;

@@ -39,6 +39,32 @@ __host__ __device__ static inline int flow_dx(uint32_t f) { return (int)(int16_t
 __device__ static inline uint32_t flow_bias(uint32_t f) { return f ^ 0x80008000u; }
 __device__ static inline uint32_t flow_l1_biased(uint32_t a, uint32_t b) { return __builtin_amdgcn_sad_u16(a, b, 0u); }
 
+// ---- descriptor storage: float32 rows of 68 values (272 bytes), or -- DFLOW_FLAG_DESCR_F16 -- binary16 rows of 68 values
+// + 4 zero pads (144 bytes, 16-byte aligned).  Arithmetic is always on the values widened to float32.
+#define DFLOW_DESC_PITCH_H 72
+typedef _Float16 dflow_h8 __attribute__((ext_vector_type(8)));
+template <typename T> struct DescPitch { static constexpr int value = DFLOW_DESC; };
+template <> struct DescPitch<_Float16> { static constexpr int value = DFLOW_DESC_PITCH_H; };
+static inline bool descr_f16(const dflow_params *p) { return (p->flags & DFLOW_FLAG_DESCR_F16) != 0; }
+
+// the descriptor of pixel pix into registers
+template <typename T> __device__ static inline void desc_load_row(float (&q)[DFLOW_DESC], const T *__restrict__ base, size_t pix)
+{
+    if constexpr (sizeof(T) == 4) {
+        const float4 *s = reinterpret_cast<const float4 *>(base + pix * DFLOW_DESC);
+#pragma unroll
+        for (int k = 0; k < DFLOW_DESC / 4; k++) { float4 v = s[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
+    } else {
+        const dflow_h8 *s = reinterpret_cast<const dflow_h8 *>(base + pix * DFLOW_DESC_PITCH_H);
+#pragma unroll
+        for (int k = 0; k < DFLOW_DESC_PITCH_H / 8; k++) {
+            const dflow_h8 v = s[k];
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (8 * k + j < DFLOW_DESC) q[8 * k + j] = (float)v[j];
+        }
+    }
+}
+
 // numpy float32 pairwise-sum order for 68 contiguous values (np.sum at daisy i flann.py:179,229)
 __device__ static inline float np_pairwise_sum68(const float *a)
 {
@@ -80,23 +106,41 @@ __device__ __noinline__ static float l1_cost_np(const float *__restrict__ a, con
     return res;
 }
 
+// the same for binary16 rows (both rows widened to float32 first; same summation order)
+__device__ __noinline__ static float l1_cost_np(const _Float16 *__restrict__ a, const _Float16 *__restrict__ b)
+{
+    float u[DFLOW_DESC], v[DFLOW_DESC], r[8];
+    desc_load_row(u, a, 0); desc_load_row(v, b, 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = fabsf(u[j] - v[j]);
+#pragma unroll
+    for (int i = 8; i < 64; i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = r[j] + fabsf(u[i + j] - v[i + j]);
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int i = 64; i < DFLOW_DESC; i++) res = res + fabsf(u[i] - v[i]);
+    return res;
+}
+
 // error plumbing (abi.hip)
 int dflow_set_error(int code, const char *fmt, ...);
 int dflow_check_launch(const char *what);
 int dflow_check_params(const dflow_params *p);
 
 // stage launchers (one per .hip file)
-int launch_daisy(const dflow_params *p, const uint8_t *bgr, float *descr, void *ws, hipStream_t s);
+int launch_daisy(const dflow_params *p, const uint8_t *bgr, void *descr, void *ws, hipStream_t s);
 size_t daisy_ws_bytes(const dflow_params *p);
-int launch_knn(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+// d1, d2: float32 (H,W,68) or, with DFLOW_FLAG_DESCR_F16, binary16 (H,W,72)
+int launch_knn(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                int32_t *nprop, int32_t *bestlabels, hipStream_t s);
 #define KNN_MFMA_EVENTS 7
-int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+int launch_knn_mfma(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                     int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s, hipEvent_t *ev = nullptr);
 double knn_mfma_issued(const dflow_params *p);
 size_t knn_mfma_ws_bytes(const dflow_params *p);
 bool knn_mfma_supported(const dflow_params *p);
-int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+int launch_neighbour(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                      int32_t *nprop, const int32_t *bestlabels, void *ws, hipStream_t s);
 size_t neighbour_ws_bytes(const dflow_params *p);
 int launch_bcd_phase(const dflow_params *p, const uint32_t *proposals, const int32_t *nprop, int32_t *bestlabels, int phase,

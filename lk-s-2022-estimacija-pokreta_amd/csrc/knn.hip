@@ -26,26 +26,40 @@ struct Top5 {
 };
 
 // exact search of one candidate cell for the query held in q[]; gd2 must be a __restrict__ kernel argument
-__device__ static inline void search_cell_exact(const float (&q)[DFLOW_DESC], const float *__restrict__ gd2, const Geom &g,
+// squared L2 distance of the query to the candidate row c (wave-uniform address: scalar loads), sequential fmaf chain
+template <typename T> __device__ static inline float canon_dist(const float (&q)[DFLOW_DESC], const T *__restrict__ c)
+{
+    float acc = 0.0f;
+    if constexpr (sizeof(T) == 4) {
+        const float4 *__restrict__ c4 = reinterpret_cast<const float4 *>(c);
+#pragma unroll
+        for (int k = 0; k < DFLOW_DESC / 4; k++) {
+            float4 v = c4[k];
+            float e;
+            e = q[4 * k] - v.x; acc = __fmaf_rn(e, e, acc);
+            e = q[4 * k + 1] - v.y; acc = __fmaf_rn(e, e, acc);
+            e = q[4 * k + 2] - v.z; acc = __fmaf_rn(e, e, acc);
+            e = q[4 * k + 3] - v.w; acc = __fmaf_rn(e, e, acc);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < DFLOW_DESC; k++) { const float e = q[k] - (float)c[k]; acc = __fmaf_rn(e, e, acc); }
+    }
+    return acc;
+}
+
+template <typename T>
+__device__ static inline void search_cell_exact(const float (&q)[DFLOW_DESC], const T *__restrict__ gd2, const Geom &g,
                                                 int ci, int cj, Top5 &t)
 {
+    constexpr int P = DescPitch<T>::value;
     const int cx0 = g.x0(ci), cx1 = g.x1(ci), cy0 = g.y0(cj), cy1 = g.y1(cj), ccw = cx1 - cx0;
     t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
     t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
     for (int yy = cy0; yy < cy1; yy++) {
-        const float4 *__restrict__ row = reinterpret_cast<const float4 *>(gd2 + ((size_t)yy * g.W + cx0) * DFLOW_DESC);
+        const T *__restrict__ row = gd2 + ((size_t)yy * g.W + cx0) * P;
         for (int xx = 0; xx < ccw; xx++) {
-            const float4 *__restrict__ c = row + xx * (DFLOW_DESC / 4);   // wave-uniform address
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < DFLOW_DESC / 4; k++) {
-                float4 v = c[k];
-                float e;
-                e = q[4 * k] - v.x; acc = __fmaf_rn(e, e, acc);
-                e = q[4 * k + 1] - v.y; acc = __fmaf_rn(e, e, acc);
-                e = q[4 * k + 2] - v.z; acc = __fmaf_rn(e, e, acc);
-                e = q[4 * k + 3] - v.w; acc = __fmaf_rn(e, e, acc);
-            }
+            const float acc = canon_dist(q, row + (size_t)xx * P);   // wave-uniform address
             if (acc < t.d4) {
                 // insert keeping ascending order; strict '<' leaves equal distances in index order; once the new
                 // entry has found its place every later entry shifts down unconditionally (a displaced entry must
@@ -60,9 +74,10 @@ __device__ static inline void search_cell_exact(const float (&q)[DFLOW_DESC], co
 }
 
 // daisy i flann.py:174-180: proposals [dy,dx] and truncated L1 costs of the 5 winners of one cell
+template <typename T>
 __device__ static inline void emit_cell(const Top5 &t, const Geom &g, int ci, int cj, size_t pix, int qy, int qx, int slot,
-                                        int LP, float tphi, bool active, const float *__restrict__ gd1,
-                                        const float *__restrict__ gd2, uint32_t *__restrict__ gproposals,
+                                        int LP, float tphi, bool active, const T *__restrict__ gd1,
+                                        const T *__restrict__ gd2, uint32_t *__restrict__ gproposals,
                                         float *__restrict__ glcosts, float *cost_out)
 {
     const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0;
@@ -70,7 +85,7 @@ __device__ static inline void emit_cell(const Top5 &t, const Geom &g, int ci, in
 #pragma unroll
     for (int qq = 0; qq < 5; qq++) {
         const int ty = cy0 + idx[qq] / ccw, tx = cx0 + idx[qq] % ccw;
-        const float s = l1_cost_np(gd1 + pix * DFLOW_DESC, gd2 + ((size_t)ty * g.W + tx) * DFLOW_DESC);
+        const float s = l1_cost_np(gd1 + pix * DescPitch<T>::value, gd2 + ((size_t)ty * g.W + tx) * DescPitch<T>::value);
         const float c = s < tphi ? s : tphi;   // python min(tphi, s)
         if (active) {
             gproposals[pix * LP + slot + qq] = pack_flow(ty - qy, tx - qx);
@@ -80,17 +95,11 @@ __device__ static inline void emit_cell(const Top5 &t, const Geom &g, int ci, in
     }
 }
 
-__device__ static inline void load_query(float (&q)[DFLOW_DESC], const float *__restrict__ gd1, size_t pix)
-{
-    const float4 *s = reinterpret_cast<const float4 *>(gd1 + pix * DFLOW_DESC);
-#pragma unroll
-    for (int k = 0; k < DFLOW_DESC / 4; k++) { float4 v = s[k]; q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w; }
-}
-
 // gd2 is only ever read and never aliases the outputs: with __restrict__ kernel arguments the compiler can prove it
 // and turns the wave-uniform candidate loads into scalar loads.
-__global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, const float *__restrict__ gd1,
-                                                                   const float *__restrict__ gd2,
+template <typename T>
+__global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, const T *__restrict__ gd1,
+                                                                   const T *__restrict__ gd2,
                                                                    uint32_t *__restrict__ gproposals,
                                                                    float *__restrict__ glcosts,
                                                                    int32_t *__restrict__ gnprop,
@@ -107,7 +116,7 @@ __global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, co
     const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
     const size_t pix = (size_t)qy * g.W + qx;
     float q[DFLOW_DESC];
-    load_query(q, gd1, pix);
+    desc_load_row(q, gd1, pix);
     const int cimin = max(0, qci - g.win), cimax = min(g.ncx - 1, qci + g.win);
     const int cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
     float mind = 1000.0f;   // mindists, daisy i flann.py:93
@@ -146,7 +155,8 @@ __device__ static inline void top5_insert(Top5 &t, float cd, int cidx)
 #undef CSWAP
 }
 
-__global__ void __launch_bounds__(64 * KNN_FIX_WAVES) knn_fix_kernel(KnnArgs a, const float *__restrict__ gd1, const float *__restrict__ gd2,
+template <typename T>
+__global__ void __launch_bounds__(64 * KNN_FIX_WAVES) knn_fix_kernel(KnnArgs a, const T *__restrict__ gd1, const T *__restrict__ gd2,
                                                         uint32_t *__restrict__ gproposals, float *__restrict__ glcosts,
                                                         const int *__restrict__ ovf_count, const int4 *__restrict__ ovf_list,
                                                         int ovf_cap, const int *__restrict__ flags, int qwaves)
@@ -185,26 +195,17 @@ __global__ void __launch_bounds__(64 * KNN_FIX_WAVES) knn_fix_kernel(KnnArgs a, 
         const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
         const int slot = 5 * ((ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin));
         float q[DFLOW_DESC];
-        load_query(q, gd1, pix);
+        desc_load_row(q, gd1, pix);
+        constexpr int P = DescPitch<T>::value;
         // ---- this wave's rows of the candidate cell
         const int cx0 = g.x0(ci), cy0 = g.y0(cj), cy1 = g.y1(cj), ccw = g.x1(ci) - cx0;
         Top5 t;
         t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
         t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
         for (int yy = cy0 + wave; yy < cy1; yy += KNN_FIX_WAVES) {
-            const float4 *__restrict__ row = reinterpret_cast<const float4 *>(gd2 + ((size_t)yy * g.W + cx0) * DFLOW_DESC);
+            const T *__restrict__ row = gd2 + ((size_t)yy * g.W + cx0) * P;
             for (int xx = 0; xx < ccw; xx++) {
-                const float4 *__restrict__ c = row + xx * (DFLOW_DESC / 4);   // wave-uniform address
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < DFLOW_DESC / 4; k++) {
-                    float4 v = c[k];
-                    float e;
-                    e = q[4 * k] - v.x; acc = __fmaf_rn(e, e, acc);
-                    e = q[4 * k + 1] - v.y; acc = __fmaf_rn(e, e, acc);
-                    e = q[4 * k + 2] - v.z; acc = __fmaf_rn(e, e, acc);
-                    e = q[4 * k + 3] - v.w; acc = __fmaf_rn(e, e, acc);
-                }
+                const float acc = canon_dist(q, row + (size_t)xx * P);   // wave-uniform address
                 if (acc < t.d4) top5_insert(t, acc, (yy - cy0) * ccw + xx);
             }
         }
@@ -232,7 +233,7 @@ __global__ void __launch_bounds__(64 * KNN_FIX_WAVES) knn_fix_kernel(KnnArgs a, 
     }
 }
 
-int launch_knn(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+int launch_knn(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                int32_t *nprop, int32_t *bestlabels, hipStream_t s)
 {
     KnnArgs a;
@@ -241,11 +242,14 @@ int launch_knn(const dflow_params *p, const float *d1, const float *d2, uint32_t
     int maxpts = (a.g.x1(a.g.ncx - 1) - a.g.x0(a.g.ncx - 1)) * (a.g.y1(a.g.ncy - 1) - a.g.y0(a.g.ncy - 1));
     a.chunks = (maxpts + KNN_THREADS - 1) / KNN_THREADS;
     int nblocks = a.g.ncx * a.g.ncy * a.chunks;
-    hipLaunchKernelGGL(knn_exact_kernel, dim3(nblocks), dim3(KNN_THREADS), 0, s, a, d1, d2, proposals, lcosts, nprop, bestlabels);
+    if (descr_f16(p))
+        hipLaunchKernelGGL(knn_exact_kernel<_Float16>, dim3(nblocks), dim3(KNN_THREADS), 0, s, a, (const _Float16 *)d1, (const _Float16 *)d2, proposals, lcosts, nprop, bestlabels);
+    else
+        hipLaunchKernelGGL(knn_exact_kernel<float>, dim3(nblocks), dim3(KNN_THREADS), 0, s, a, (const float *)d1, (const float *)d2, proposals, lcosts, nprop, bestlabels);
     return dflow_check_launch("knn_exact_kernel");
 }
 
-int launch_knn_fix(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+int launch_knn_fix(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                    const int *ovf_count, const int4 *ovf_list, int ovf_cap, const int *flags, hipStream_t s)
 {
     KnnArgs a;
@@ -253,7 +257,11 @@ int launch_knn_fix(const dflow_params *p, const float *d1, const float *d2, uint
     a.LP = p->label_pitch; a.tphi = p->tphi; a.chunks = 0;
     int maxpts = (a.g.x1(a.g.ncx - 1) - a.g.x0(a.g.ncx - 1)) * (a.g.y1(a.g.ncy - 1) - a.g.y0(a.g.ncy - 1));
     int qwaves = (maxpts + 63) / 64;
-    hipLaunchKernelGGL(knn_fix_kernel, dim3(1024), dim3(64 * KNN_FIX_WAVES), 0, s, a, d1, d2, proposals, lcosts, ovf_count, ovf_list, ovf_cap,
-                       flags, qwaves);
+    if (descr_f16(p))
+        hipLaunchKernelGGL(knn_fix_kernel<_Float16>, dim3(1024), dim3(64 * KNN_FIX_WAVES), 0, s, a, (const _Float16 *)d1, (const _Float16 *)d2, proposals,
+                           lcosts, ovf_count, ovf_list, ovf_cap, flags, qwaves);
+    else
+        hipLaunchKernelGGL(knn_fix_kernel<float>, dim3(1024), dim3(64 * KNN_FIX_WAVES), 0, s, a, (const float *)d1, (const float *)d2, proposals,
+                           lcosts, ovf_count, ovf_list, ovf_cap, flags, qwaves);
     return dflow_check_launch("knn_fix_kernel");
 }

@@ -112,14 +112,15 @@ __host__ __device__ static inline size_t km_total_rows(const Geom &g)
 
 // mu = mean descriptor over KM_MEAN_SAMPLES (1024: the single block is latency-bound) evenly spaced pixels of image 2: one block, thread = (dimension, sample group),
 // partial sums combined in a fixed order.  Any mu gives exact results; a good one makes the screen tight.
-__global__ void __launch_bounds__(1024) knn_mean_kernel(const float *__restrict__ d, float *__restrict__ mu, int npix)
+template <typename T>
+__global__ void __launch_bounds__(1024) knn_mean_kernel(const T *__restrict__ d, float *__restrict__ mu, int npix)
 {
     __shared__ float part[15][DFLOW_DESC];
     const int k = threadIdx.x % DFLOW_DESC, grp = threadIdx.x / DFLOW_DESC;
     const int nsamp = npix < KM_MEAN_SAMPLES ? npix : KM_MEAN_SAMPLES, stride = npix / nsamp;
     if (grp < 15) {
         float acc = 0.0f;
-        for (int sidx = grp; sidx < nsamp; sidx += 15) acc += d[(size_t)sidx * stride * DFLOW_DESC + k];
+        for (int sidx = grp; sidx < nsamp; sidx += 15) acc += (float)d[(size_t)sidx * stride * DescPitch<T>::value + k];
         part[grp][k] = acc;
     }
     __syncthreads();
@@ -141,7 +142,8 @@ __device__ static inline _Float16 km_f16_up(double v) { return (_Float16)(float)
 // 16-byte store.  Its rounding is part of E: |y^_j - y_j| <= gamma_68 sum_i |V_ji x_i| <= 68 * 2^-24 (1 + 5e-6) |x|, over
 // the 42 components |y^ - y_P| <= 2.63e-5 |x| (KM_RHO also holds the 6.2e-8 |x| of the rounding of d - mu).
 #define KM_RHO 2.65e-5
-__global__ void __launch_bounds__(256) knn_prep_kernel(const float *__restrict__ d, const float *__restrict__ mu,
+template <typename T>
+__global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, const float *__restrict__ mu,
                                                        const float *__restrict__ vt, _Float16 *__restrict__ h,
                                                        float2 *__restrict__ qs, int *__restrict__ flags, Geom g, int which)
 {
@@ -171,22 +173,17 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const float *__restrict__
         }
         pix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
     }
-    const float4 *s = reinterpret_cast<const float4 *>(d + (size_t)pix * DFLOW_DESC);
     float x[DFLOW_DESC];
+    desc_load_row(x, d, (size_t)pix);
     double sxall = 0.0;
     bool bad = false;
 #pragma unroll
-    for (int k = 0; k < DFLOW_DESC / 4; k++) {
-        float4 v = s[k];
-        float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float sc = KM_ALPHA * (e[j] - mu[4 * k + j]);   // one rounding (the subtraction); the scaling is exact
-            // too large or NaN (tested on the bits: this file is compiled with -fno-honor-nans): no f16 representation
-            bad |= (__float_as_uint(sc) & 0x7FFFFFFFu) >= 0x476A6000u;      // |sc| >= 60000, inf, NaN
-            x[4 * k + j] = sc;
-            sxall = fma((double)sc, (double)sc, sxall);          // |x|^2; |V^T x|^2 = |x|^2 (1 +- PCA_DELTA_MAX)
-        }
+    for (int k = 0; k < DFLOW_DESC; k++) {
+        const float sc = KM_ALPHA * (x[k] - mu[k]);   // one rounding (the subtraction); the scaling is exact
+        // too large or NaN (tested on the bits: this file is compiled with -fno-honor-nans): no f16 representation
+        bad |= (__float_as_uint(sc) & 0x7FFFFFFFu) >= 0x476A6000u;      // |sc| >= 60000, inf, NaN
+        x[k] = sc;
+        sxall = fma((double)sc, (double)sc, sxall);          // |x|^2; |V^T x|^2 = |x|^2 (1 +- PCA_DELTA_MAX)
     }
     double ss = 0.0, sx = 0.0, se = 0.0;        // |y~|^2, |y^|^2, |y~ - y^|^2 over the KM_KD leading components
     auto component = [&](int j) -> _Float16 {
@@ -520,8 +517,38 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 }
 
 // ------------------------------------------------------------------------------------------------ resolve
+// binary16 rows (144 bytes = 9 pieces of 16 bytes): every lane fetches its own row into registers; 9 cache accesses per row
+// instead of the 17 of a float32 row, which is what made the float32 version stage its rows through LDS (row_stage.h)
+typedef unsigned int km_u4 __attribute__((ext_vector_type(4)));
+struct RowDirectH {
+    km_u4 r[9];
+    __device__ __forceinline__ void init(char *, uint32_t *, int) {}
+    __device__ __forceinline__ void issue(rs_gptr base, uint32_t off16, bool act)
+    {
+        if (act) {
+            const __attribute__((address_space(1))) km_u4 *s = reinterpret_cast<const __attribute__((address_space(1))) km_u4 *>(base + ((unsigned long long)off16 << 4));
+#pragma unroll
+            for (int j = 0; j < 9; j++) r[j] = s[j];
+        }
+    }
+    __device__ __forceinline__ void fetch(float4 (&cv)[17])
+    {
+        float f[72];
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const dflow_h8 v = __builtin_bit_cast(dflow_h8, r[j]);
+#pragma unroll
+            for (int i = 0; i < 8; i++) f[8 * j + i] = (float)v[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 17; k++) cv[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+    }
+};
+template <bool F16> struct RowsOf { typedef RowStage type; static constexpr uint32_t PIECES = 17u; };
+template <> struct RowsOf<true> { typedef RowDirectH type; static constexpr uint32_t PIECES = 9u; };
+
 struct KmResolve {
-    const float *d1, *d2;
+    const void *d1, *d2;           // float32 (H,W,68) or binary16 (H,W,72)
     const uint32_t *ev;
     const uint8_t *ev_cnt;
     uint32_t *proposals;
@@ -558,6 +585,7 @@ __device__ static inline void key_insert(unsigned long long (&k)[5], float (&c)[
 // by the same (distance, index) keys, so the results are identical.
 #define KM_EVLIST2 30            // candidates per query and candidate cell listed in LDS at a time (more: further passes);
                                  // 30: stage + lists + offsets = 20 KB per wave = 8 waves per CU
+template <bool F16>
 __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve p)
 {
     const Geom g = a.g;
@@ -574,10 +602,11 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
     const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
     const int cx0 = g.x0(ci), ccw = g.x1(ci) - cx0;
 
-    __shared__ __attribute__((aligned(1024))) char stage[ROW_STAGE_BYTES];   // row_stage.h
+    __shared__ __attribute__((aligned(1024))) char stage[F16 ? 16 : ROW_STAGE_BYTES];   // row_stage.h (float32 rows only)
     __shared__ uint16_t evl[KM_EVLIST2][64];                          // this query's candidate indices, [slot][lane]
     __shared__ __attribute__((aligned(16))) uint32_t s_cand[64];      // row offsets (16-byte units) of the round, [lane & 3][lane >> 2]
-    RowStage rows;
+    typename RowsOf<F16>::type rows;
+    constexpr uint32_t PIECES = RowsOf<F16>::PIECES;          // 16-byte units per descriptor row
     rows.init(stage, s_cand, lane);
     // ---- the queries of this wave
     float q[DFLOW_DESC];
@@ -587,7 +616,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
     const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
     const size_t qpix = (size_t)qy * g.W + qx;
     {
-        rows.issue((rs_gptr)p.d1, (uint32_t)qpix * 17u, true);
+        rows.issue((rs_gptr)p.d1, (uint32_t)qpix * PIECES, true);
         float4 qv[17];
         rows.fetch(qv);
 #pragma unroll
@@ -656,7 +685,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
         auto issue_cand = [&](int e) -> int {
             const bool act = e < nev;
             const int idx = act ? evl[e][lane] : 0;
-            rows.issue(d2g, (uint32_t)((cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * 17u, act);
+            rows.issue(d2g, (uint32_t)((cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * PIECES, act);
             return idx;
         };
         if (__ballot(nev > 0)) {
@@ -775,11 +804,11 @@ bool knn_mfma_supported(const dflow_params *p)
     return max_cell_points(g) <= KM_MAXPTS && p->window >= 0 && p->window <= 2;
 }
 
-int launch_knn_fix(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+int launch_knn_fix(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                    const int *ovf_count, const int4 *ovf_list, int ovf_cap, const int *flags, hipStream_t s);
 
 // ev (optional, profiling): KNN_MFMA_EVENTS events recorded on s at the boundaries basis | prep | screen | resolve | fix | finalize
-int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+int launch_knn_mfma(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                     int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s, hipEvent_t *tev)
 {
     auto mark = [&](int k) { if (tev) (void)hipEventRecord(tev[k], s); };
@@ -804,13 +833,20 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
         return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_knn_mfma");
     int nb = (int)((N + 255) / 256);
     mark(0);
-    hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(1024), 0, s, d2, mu, (int)N);
-    int rc = launch_knn_pca(d2, mu, vt, ctr + 1, pca_ws, (int)N, s);
+    const bool f16 = descr_f16(p);
+    if (f16) hipLaunchKernelGGL(knn_mean_kernel<_Float16>, dim3(1), dim3(1024), 0, s, (const _Float16 *)d2, mu, (int)N);
+    else hipLaunchKernelGGL(knn_mean_kernel<float>, dim3(1), dim3(1024), 0, s, (const float *)d2, mu, (int)N);
+    int rc = launch_knn_pca(d2, f16, mu, vt, ctr + 1, pca_ws, (int)N, s);
     if (rc) return rc;
     mark(1);
-    hipLaunchKernelGGL(knn_prep_kernel, dim3(nb), dim3(256), 0, s, d1, (const float *)mu, (const float *)vt, h1, qs, ctr + 1, g, 0);
-    hipLaunchKernelGGL(knn_prep_kernel, dim3((km_pad(max_cell_points(g)) + 255) / 256, g.ncx * g.ncy), dim3(256), 0, s, d2,
-                       (const float *)mu, (const float *)vt, h2, (float2 *)nullptr, ctr + 1, g, 1);
+    const dim3 cgrid((km_pad(max_cell_points(g)) + 255) / 256, g.ncx * g.ncy);
+    if (f16) {
+        hipLaunchKernelGGL(knn_prep_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16 *)d1, (const float *)mu, (const float *)vt, h1, qs, ctr + 1, g, 0);
+        hipLaunchKernelGGL(knn_prep_kernel<_Float16>, cgrid, dim3(256), 0, s, (const _Float16 *)d2, (const float *)mu, (const float *)vt, h2, (float2 *)nullptr, ctr + 1, g, 1);
+    } else {
+        hipLaunchKernelGGL(knn_prep_kernel<float>, dim3(nb), dim3(256), 0, s, (const float *)d1, (const float *)mu, (const float *)vt, h1, qs, ctr + 1, g, 0);
+        hipLaunchKernelGGL(knn_prep_kernel<float>, cgrid, dim3(256), 0, s, (const float *)d2, (const float *)mu, (const float *)vt, h2, (float2 *)nullptr, ctr + 1, g, 1);
+    }
 
     mark(2);
     KmGeom a;
@@ -828,7 +864,8 @@ int launch_knn_mfma(const dflow_params *p, const float *d1, const float *d2, uin
     KmResolve rs;
     rs.d1 = d1; rs.d2 = d2; rs.ev = ev; rs.ev_cnt = ev_cnt; rs.proposals = proposals; rs.lcosts = lcosts;
     rs.ovf_count = ctr; rs.ovf_list = ovf; rs.ovf_cap = KM_OVF_CAP;
-    hipLaunchKernelGGL(knn_resolve_kernel, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
+    if (f16) hipLaunchKernelGGL(knn_resolve_kernel<true>, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
+    else hipLaunchKernelGGL(knn_resolve_kernel<false>, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
     rc = dflow_check_launch("knn_resolve_kernel");
     if (rc) return rc;
     mark(4);

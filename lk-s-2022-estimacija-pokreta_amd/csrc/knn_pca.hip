@@ -24,14 +24,15 @@
 #define PCA_SWEEPS 5
 #endif
 
-__global__ void __launch_bounds__(256) knn_cov_kernel(const float *__restrict__ d, const float *__restrict__ mu,
+template <typename T>
+__global__ void __launch_bounds__(256) knn_cov_kernel(const T *__restrict__ d, const float *__restrict__ mu,
                                                       double *__restrict__ partial, int npix)
 {
     __shared__ float xs[PCA_BLOCK_SAMPLES][PCA_LD];
     const int nsamp = npix < PCA_SAMPLES ? npix : PCA_SAMPLES, stride = npix / nsamp;
     for (int e = threadIdx.x; e < PCA_BLOCK_SAMPLES * PCA_N; e += 256) {
         const int sl = e / PCA_N, k = e % PCA_N, sidx = blockIdx.x * PCA_BLOCK_SAMPLES + sl;
-        xs[sl][k] = sidx < nsamp ? d[(size_t)sidx * stride * PCA_N + k] - mu[k] : 0.0f;
+        xs[sl][k] = sidx < nsamp ? (float)d[(size_t)sidx * stride * DescPitch<T>::value + k] - mu[k] : 0.0f;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < PCA_N * PCA_N; e += 256) {
@@ -214,10 +215,11 @@ __global__ void __launch_bounds__(1024) knn_jacobi_kernel(const double *__restri
 
 size_t knn_pca_ws_bytes(void) { return (size_t)PCA_BLOCKS * PCA_N * PCA_N * sizeof(double); }
 
-int launch_knn_pca(const float *d2, const float *mu, float *vt, int *flags, void *ws, int npix, hipStream_t s)
+int launch_knn_pca(const void *d2, bool f16, const float *mu, float *vt, int *flags, void *ws, int npix, hipStream_t s)
 {
     double *partial = (double *)ws;
-    hipLaunchKernelGGL(knn_cov_kernel, dim3(PCA_BLOCKS), dim3(256), 0, s, d2, mu, partial, npix);
+    if (f16) hipLaunchKernelGGL(knn_cov_kernel<_Float16>, dim3(PCA_BLOCKS), dim3(256), 0, s, (const _Float16 *)d2, mu, partial, npix);
+    else hipLaunchKernelGGL(knn_cov_kernel<float>, dim3(PCA_BLOCKS), dim3(256), 0, s, (const float *)d2, mu, partial, npix);
     hipLaunchKernelGGL(knn_jacobi_kernel, dim3(1), dim3(1024), 0, s, (const double *)partial, vt, flags);
     return dflow_check_launch("knn_jacobi_kernel");
 }

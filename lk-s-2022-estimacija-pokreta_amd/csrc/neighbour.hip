@@ -15,7 +15,7 @@ struct NbrArgs {
     int LP, L, K, ngauss, max_attempts;
     float tphi;
     uint32_t k0, k1;
-    const float *d1, *d2;
+    const void *d1, *d2;       // float32 (H,W,68) or binary16 (H,W,72) rows
     uint32_t *proposals;
     float *lcosts;
     int32_t *nprop;
@@ -75,7 +75,7 @@ __global__ void nbr_bestflow_kernel(const uint32_t *__restrict__ proposals, cons
     if (pix < n) bestflow[pix] = proposals[(size_t)pix * LP + bestlabels[pix]];
 }
 
-__global__ void __launch_bounds__(NBR_THREADS) neighbour_kernel(NbrArgs a)
+template <typename T> __global__ void __launch_bounds__(NBR_THREADS) neighbour_kernel(NbrArgs a)
 {
     __shared__ uint32_t thr[128];
     extern __shared__ uint32_t s_app[];                      // [ngauss][NBR_THREADS]: the proposals this thread has appended so far
@@ -91,11 +91,7 @@ __global__ void __launch_bounds__(NBR_THREADS) neighbour_kernel(NbrArgs a)
     uint32_t *prow = a.proposals + (size_t)pix * a.LP;
     // this pixel's descriptor stays in registers for all of its draws
     float q[DFLOW_DESC];
-    {
-        const float4 *q4 = reinterpret_cast<const float4 *>(a.d1 + (size_t)pix * DFLOW_DESC);
-#pragma unroll
-        for (int k = 0; k < DFLOW_DESC / 4; k++) { const float4 u = q4[k]; q[4 * k] = u.x; q[4 * k + 1] = u.y; q[4 * k + 2] = u.z; q[4 * k + 3] = u.w; }
-    }
+    desc_load_row(q, reinterpret_cast<const T *>(a.d1), (size_t)pix);
     int np_ = a.nprop[pix], ngp = 0, i = 0;
     for (uint32_t att = 0; i < a.ngauss && att < (uint32_t)a.max_attempts; att++) {
         uint32_t r0, r1;
@@ -119,13 +115,10 @@ __global__ void __launch_bounds__(NBR_THREADS) neighbour_kernel(NbrArgs a)
         if (!dup) {
             prow[np_] = tv;                                                 // :227
             s_app[ngp * NBR_THREADS + threadIdx.x] = tv;
-            const float4 *t = reinterpret_cast<const float4 *>(a.d2 + (size_t)tpix * DFLOW_DESC);
             float diff[DFLOW_DESC];
+            desc_load_row(diff, reinterpret_cast<const T *>(a.d2), (size_t)tpix);
 #pragma unroll
-            for (int k = 0; k < DFLOW_DESC / 4; k++) {
-                const float4 v = t[k];
-                diff[4 * k] = q[4 * k] - v.x; diff[4 * k + 1] = q[4 * k + 1] - v.y; diff[4 * k + 2] = q[4 * k + 2] - v.z; diff[4 * k + 3] = q[4 * k + 3] - v.w;
-            }
+            for (int k = 0; k < DFLOW_DESC; k++) diff[k] = q[k] - diff[k];
             const float s = fabsf(np_pairwise_sum68(diff));                 // :228-229 (Q6)
             a.lcosts[(size_t)pix * a.LP + np_] = s < a.tphi ? s : a.tphi;
             np_++; ngp++;                                                   // :230-231
@@ -147,7 +140,7 @@ static void gauss_thresholds(double sigma, uint32_t *thr)
 
 size_t neighbour_ws_bytes(const dflow_params *p) { return (size_t)p->pich * p->picw * sizeof(uint32_t) + 256; }
 
-int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, uint32_t *proposals, float *lcosts,
+int launch_neighbour(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                      int32_t *nprop, const int32_t *bestlabels, void *ws, hipStream_t s)
 {
     NbrArgs a;
@@ -160,7 +153,8 @@ int launch_neighbour(const dflow_params *p, const float *d1, const float *d2, ui
     uint32_t *bestflow = (uint32_t *)ws;
     a.bestflow = bestflow;
     hipLaunchKernelGGL(nbr_bestflow_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const uint32_t *)proposals, bestlabels, bestflow, n, p->label_pitch);
-    hipLaunchKernelGGL(neighbour_kernel, dim3((n + NBR_THREADS - 1) / NBR_THREADS), dim3(NBR_THREADS),
-                       (size_t)(p->ngauss > 0 ? p->ngauss : 1) * NBR_THREADS * sizeof(uint32_t), s, a);
+    const size_t shmem = (size_t)(p->ngauss > 0 ? p->ngauss : 1) * NBR_THREADS * sizeof(uint32_t);
+    if (descr_f16(p)) hipLaunchKernelGGL(neighbour_kernel<_Float16>, dim3((n + NBR_THREADS - 1) / NBR_THREADS), dim3(NBR_THREADS), shmem, s, a);
+    else hipLaunchKernelGGL(neighbour_kernel<float>, dim3((n + NBR_THREADS - 1) / NBR_THREADS), dim3(NBR_THREADS), shmem, s, a);
     return dflow_check_launch("neighbour_kernel");
 }

@@ -39,8 +39,9 @@ class DiscreteFlow:
         self.device = torch.device(device)
         H, W, LP = pich, picw, self.p.label_pitch
         dev = self.device
-        self.descrs1 = torch.empty((H, W, 68), dtype=torch.float32, device=dev)     # daisy i flann.py:80
-        self.descrs2 = torch.empty((H, W, 68), dtype=torch.float32, device=dev)     # :81
+        # float32 (H,W,68), or with DFLOW_FLAG_DESCR_F16 binary16 (H,W,72): 68 values + 4 zero pads per pixel (include/dflow.h)
+        self.descrs1 = self._new_descr()                                             # daisy i flann.py:80
+        self.descrs2 = self._new_descr()                                             # :81
         self.proposals = torch.empty((H, W, LP), dtype=torch.int32, device=dev)     # :89 (packed int16 pairs)
         self.lcosts = torch.empty((H, W, LP), dtype=torch.float32, device=dev)      # :90
         self.nprop = torch.empty((H, W), dtype=torch.int32, device=dev)             # :91
@@ -52,6 +53,16 @@ class DiscreteFlow:
         self._bcd_ready = False     # compat matrices in the workspace are valid for the current proposals
 
     # ------------------------------------------------------------------ helpers
+    @property
+    def descr_f16(self):
+        return bool(self.p.flags & _lib.FLAG_DESCR_F16)
+
+    def _new_descr(self):
+        H, W = self.p.pich, self.p.picw
+        if self.descr_f16:
+            return torch.zeros((H, W, _lib.DESC_PITCH_F16), dtype=torch.float16, device=self.device)
+        return torch.empty((H, W, 68), dtype=torch.float32, device=self.device)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -60,7 +71,8 @@ class DiscreteFlow:
 
     # ------------------------------------------------------------------ reference-named stages
     def izracunajDaisy(self, picture, out=None):
-        """daisy i flann.py:69-77.  picture: (H,W,3) uint8 BGR (numpy or device tensor) -> (H,W,68) f32 tensor."""
+        """daisy i flann.py:69-77.  picture: (H,W,3) uint8 BGR (numpy or device tensor) -> (H,W,68) f32 tensor (with
+        DFLOW_FLAG_DESCR_F16: (H,W,72) binary16, see descriptors_f32)."""
         H, W = self.p.pich, self.p.picw
         if isinstance(picture, np.ndarray):
             if picture.shape != (H, W, 3) or picture.dtype != np.uint8:
@@ -72,7 +84,7 @@ class DiscreteFlow:
                 raise ValueError("picture must be a contiguous uint8 (%d,%d,3) tensor" % (H, W))
             img = picture
         if out is None:
-            out = torch.empty((H, W, 68), dtype=torch.float32, device=self.device)
+            out = self._new_descr()
         self._bcd_ready = False
         _lib.check(_lib.lib().dflow_daisy(self._pp(), img.data_ptr(), out.data_ptr(), self.ws.data_ptr(),
                                           self.ws_bytes, self._stream()), "dflow_daisy")
@@ -84,12 +96,13 @@ class DiscreteFlow:
         self.izracunajDaisy(pic4, out=self.descrs2)
 
     def set_descriptors(self, descrs1, descrs2):
-        self.descrs1.copy_(torch.as_tensor(descrs1, dtype=torch.float32))
-        self.descrs2.copy_(torch.as_tensor(descrs2, dtype=torch.float32))
+        """(H,W,68) arrays -> the descriptor planes (rounded to binary16 if the pass stores them that way)."""
+        for dst, src in ((self.descrs1, descrs1), (self.descrs2, descrs2)):
+            dst[..., :68].copy_(torch.as_tensor(src, dtype=torch.float32).to(dst.dtype))
 
     def descriptors_f32(self, which):
         """Descriptors of image `which` (0: first, 1: second) as an (H,W,68) float32 tensor, whatever the storage."""
-        return (self.descrs1, self.descrs2)[which].to(torch.float32)
+        return (self.descrs1, self.descrs2)[which][..., :68].to(torch.float32)
 
     def generisi(self):
         """napraviCD2 + generisi, daisy i flann.py:144-189."""

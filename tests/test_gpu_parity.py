@@ -293,8 +293,8 @@ def test_kitti_config5_as_stated_matches_oracle(torch_, oracle, synth):
     O.set_threads(16)
     try:
         img1, img2, _ = synth.make_pair(H, W, seed=H + W + 1)
-        df = make(H, W, ch, cw, seed=4)
-        df.p.flags = L.FLAG_DESCR_F16
+        df = pkg("pipeline").DiscreteFlow(H, W, ch, cw, seed=4, flags=L.FLAG_DESCR_F16)
+        assert df.descrs1.dtype == torch_.float16 and df.descrs1.shape[-1] == 72          # real half-width descriptor planes
         p = oracle_params(O, df)
         df.load_pair(img1, img2)
         d1 = O.daisy(img1).astype(np.float16).astype(np.float32)
@@ -750,14 +750,24 @@ def test_fp16_descriptor_mode_matches_oracle(torch_, oracle, synth):
     L = pkg("_lib")
     H, W, ch, cw = 60, 84, 10, 12
     img1, img2, _ = synth.make_pair(H, W, seed=31, amp_x=7.0, amp_y=5.0)
-    df = make(H, W, ch, cw, seed=9)
-    df.p.flags = L.FLAG_DESCR_F16
+    df = pkg("pipeline").DiscreteFlow(H, W, ch, cw, seed=9, flags=L.FLAG_DESCR_F16)
     p = O.make_params(H, W, ch, cw, seed=9)
     df.load_pair(img1, img2)
     d1 = O.daisy(img1).astype(np.float16).astype(np.float32)
     d2 = O.daisy(img2).astype(np.float16).astype(np.float32)
-    assert np.array_equal(df.descrs1.cpu().numpy().view(np.uint32), d1.view(np.uint32))
-    assert np.array_equal(df.descrs2.cpu().numpy().view(np.uint32), d2.view(np.uint32))
+    assert df.descrs1.dtype == torch_.float16 and tuple(df.descrs1.shape) == (H, W, 72)      # half-width storage, 144-byte rows
+    assert np.array_equal(df.descrs1[..., :68].cpu().numpy().view(np.uint16), O.daisy(img1).astype(np.float16).view(np.uint16))
+    assert not df.descrs1[..., 68:].any() and not df.descrs2[..., 68:].any()
+    assert np.array_equal(df.descriptors_f32(0).cpu().numpy().view(np.uint32), d1.view(np.uint32))
+    assert np.array_equal(df.descriptors_f32(1).cpu().numpy().view(np.uint32), d2.view(np.uint32))
+    # the brute-force kernel reads the same planes: its results must equal the MFMA-screened ones
+    df.p.flags = L.FLAG_DESCR_F16 | L.FLAG_KNN_EXACT
+    df.generisi()
+    exact = [t.clone() for t in (df.proposals, df.lcosts, df.nprop, df.bestlabels)]
+    df.p.flags = L.FLAG_DESCR_F16
+    df.generisi()
+    for a_, b_ in zip(exact, (df.proposals, df.lcosts, df.nprop, df.bestlabels)):
+        assert torch_.equal(a_, b_)
     assert not np.array_equal(d1, O.daisy(img1))                     # the mode does change the values
     df.generisi()
     pr, lc, npr, bl = O.knn_proposals(p, d1, d2)
