@@ -32,10 +32,27 @@
 #define BCD_LDS_LABELS 256
 #define BCD_TB_STEPS 32                  // traceback chunk (steps) staged in LDS
 #define BCD_GROUPS 3                     // 64-label waves per pixel
+// Reserved second / third blocks per 64-label wave.  21 % / 2.6 % of the labels own one (mean 13 / 1.6 per wave of kNN
+// labels, scratch/list_stats.py: more than 40 / 24 on 0.1 % of the waves; the third wave holds the 22 neighbour labels: never
+// more than 16 / 8); a label whose block does not fit (and every label with more than 15 members) is marked "more" and
+// continues in its 160-bit row.  Those rows are bump-allocated from a pool (BCD_POOL_DIV-th of the worst case); a row that
+// does not fit the pool is not stored and the chain kernel tests that label's remaining predecessors one by one.
+#define BCD_CAP_B01 40                   // waves 0 and 1
+#define BCD_CAP_B2 16                    // wave 2 (22 labels at most)
+#define BCD_CAP_C01 24
+#define BCD_CAP_C2 8
+#define BCD_ROW_B (2 * BCD_CAP_B01 + BCD_CAP_B2)        // slots per (pixel, direction): second blocks, then the third blocks
+#define BCD_ROW_C (2 * BCD_CAP_C01 + BCD_CAP_C2)
+#define BCD_ROW_BC (BCD_ROW_B + BCD_ROW_C + 2)     // + 16 bytes: first pool row of each wave's labels marked "more" (3 x uint32)
+#define BCD_POOL_DIV 32
 
 // 8-byte block: x = member indices k0..k3 (bytes, increasing, 0xFF = none: reads the +inf tail of dp);
 //               y = k4 | pair costs (nibble j = |dy-dy'|+|dx-dx'| < tpsi <= 8 of member j) << 8 | first block only:
-//                   bit 11 = "more than 15 members", bits 28..31 = min(count, 15)
+//                   bit 11 = "more": members beyond the blocks that are stored, bit 15 = second block stored, bit 19 = third
+//                   block stored (the top bits of the cost nibbles are free), bits 28..31 = min(count, 15), 15 if "more"
+#define BLK_MORE 0x800u
+#define BLK_HAS_B 0x8000u
+#define BLK_HAS_C 0x80000u
 #define BLK_EMPTY_X 0xFFFFFFFFu
 #define BLK_EMPTY_Y 0x000000FFu
 
@@ -53,8 +70,10 @@ struct BcdPlanes {
     uint8_t *back;                   // back-pointers of the running phase [chain][step][192 threads]
     uint2 *lab;                      // [pix][LP]            {biased flow, data cost}
     uint2 *blkA;                     // [pix][2][LP]         first block of every label
-    uint2 *blkB, *blkC;              // [pix][2][3][64]      second / third blocks, compacted per 64-label wave
-    uint32_t *masks;                 // [pix][2][LP][5]      160-bit rows (rows with more than 15 members only)
+    uint2 *blkBC;                    // [pix][2][BCD_ROW_BC] second blocks (BCD_ROW_B slots), third blocks, compacted per 64-label wave; pool bases
+    uint32_t *masks;                 // [pool_rows][5]       160-bit rows of the labels marked "more", bump-allocated
+    uint32_t *cursor;                // next free pool row (zeroed before bcd_lists_kernel runs)
+    uint32_t pool_rows;
 };
 
 template <int V> struct BcdC { static constexpr int value = V; };
@@ -123,7 +142,7 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
     };
     if (tn > 128) build(BcdC<1>()); else build(BcdC<0>());
     const size_t rowbase = ((size_t)pix * 2 + dir) * (size_t)LP;
-    const size_t grpbase = ((size_t)pix * 2 + dir) * (size_t)(BCD_GROUPS * 64);
+    const size_t pdbase = (size_t)pix * 2 + dir;
 #pragma unroll
     for (int grp = 0; grp < 3; grp++) {
         const int tl = 64 * grp + lane;
@@ -168,22 +187,38 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
         }
         // bytes 0..3 | 4, 5..8 | 9, 10..13 | 14 and nibbles 0..4, 5..9, 10..14 -> the three blocks
         const unsigned long long pp = ((unsigned long long)p1 << 32) | p0;
+        // second / third blocks: compacted per wave in lane order (rank = number of lower lanes that own one); the first
+        // BCD_CAP_B / BCD_CAP_C owners get a slot
+        const unsigned long long hasB = __ballot(cnt > BCD_BLK), hasC = __ballot(cnt > 2 * BCD_BLK);
+        const uint32_t rankB = __builtin_amdgcn_mbcnt_hi((uint32_t)(hasB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasB, 0u));
+        const uint32_t rankC = __builtin_amdgcn_mbcnt_hi((uint32_t)(hasC >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasC, 0u));
+        const uint32_t capB = grp < 2 ? BCD_CAP_B01 : BCD_CAP_B2, capC = grp < 2 ? BCD_CAP_C01 : BCD_CAP_C2;
+        const bool storeB = cnt > BCD_BLK && rankB < capB, storeC = cnt > 2 * BCD_BLK && storeB && rankC < capC;
+        const bool more = cnt > BCD_LIST || (cnt > BCD_BLK && !storeB) || (cnt > 2 * BCD_BLK && !storeC);
         const uint32_t ax = l0;
-        const uint32_t ay = (l1 & 0xFFu) | (((uint32_t)pp & 0xFFFFFu) << 8) | (cnt > BCD_LIST ? 0x800u : 0u) | ((uint32_t)min(cnt, 15) << 28);
+        const uint32_t ay = (l1 & 0xFFu) | (((uint32_t)pp & 0xFFFFFu) << 8) | (more ? BLK_MORE : 0u) | (storeB ? BLK_HAS_B : 0u) |
+                            (storeC ? BLK_HAS_C : 0u) | ((uint32_t)(more ? 15 : min(cnt, 15)) << 28);     // "more" reports the largest count: the
+                                                                                                       // chain kernel's block tests then lead to its row
         const uint32_t bx = __builtin_amdgcn_alignbit(l2, l1, 8);
         const uint32_t by = ((l2 >> 8) & 0xFFu) | (((uint32_t)(pp >> 20) & 0xFFFFFu) << 8);
         const uint32_t cx = __builtin_amdgcn_alignbit(l3, l2, 16);
         const uint32_t cy = ((l3 >> 16) & 0xFFu) | (((uint32_t)(pp >> 40) & 0xFFFFFu) << 8);
         if (tl < LP) pl.blkA[rowbase + tl] = make_uint2(ax, ay);
-        // second / third blocks: compacted per wave in lane order (rank = number of lower lanes that own one)
-        const unsigned long long hasB = __ballot(cnt > BCD_BLK), hasC = __ballot(cnt > 2 * BCD_BLK);
-        if (cnt > BCD_BLK) pl.blkB[grpbase + 64 * grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(hasB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasB, 0u))] = make_uint2(bx, by);
-        if (cnt > 2 * BCD_BLK) pl.blkC[grpbase + 64 * grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(hasC >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasC, 0u))] = make_uint2(cx, cy);
-        if (cnt > BCD_LIST) {
-            // the 160-bit row itself: read by the chain kernel only for rows with more than 15 members
-            uint32_t *out = pl.masks + (rowbase + tl) * BCD_MASK_WORDS;
+        if (storeB) pl.blkBC[pdbase * BCD_ROW_BC + grp * BCD_CAP_B01 + rankB] = make_uint2(bx, by);
+        if (storeC) pl.blkBC[pdbase * BCD_ROW_BC + BCD_ROW_B + grp * BCD_CAP_C01 + rankC] = make_uint2(cx, cy);
+        // the 160-bit rows of the labels marked "more": one allocation per wave from the pool, in lane order
+        const unsigned long long dense = __ballot(more);
+        if (dense) {                                         // wave-uniform
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(pl.cursor, (uint32_t)__popcll(dense));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (lane == 0) reinterpret_cast<uint32_t *>(pl.blkBC + pdbase * BCD_ROW_BC + BCD_ROW_B + BCD_ROW_C)[grp] = base;
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dense >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dense, 0u));
+            if (more && slot < pl.pool_rows) {
+                uint32_t *out = pl.masks + (size_t)slot * BCD_MASK_WORDS;
 #pragma unroll
-            for (int j = 0; j < BCD_MASK_WORDS; j++) out[j] = w[j];
+                for (int j = 0; j < BCD_MASK_WORDS; j++) out[j] = w[j];
+            }
         }
     }
 }
@@ -342,6 +377,8 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
     int32_t *g_best = ps.bestlabels;
     const uint2 *g_lab = ps.pl.lab;
     const uint32_t *g_masks = ps.pl.masks;
+    const uint2 *g_bc = ps.pl.blkBC;
+    const uint32_t pool_rows = ps.pl.pool_rows;
     uint8_t *back = ps.pl.back + ((size_t)chain * len) * BCD_BACK_PITCH;
 
     tnl = (int *)(bestf + len + 2);
@@ -361,15 +398,16 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
     // unconditional; nothing in a step waits for a load issued in the same step.  The row pointers are wave-uniform and
     // advance by a constant stride per step (scalar adds); they stop at the chain's last pixel.
     const uint32_t offl = (uint32_t)tl * 8u;
-    const long long rowl = (long long)LP * 8, rowg = (long long)(BCD_GROUPS * 64) * 8;
+    const long long rowl = (long long)LP * 8, rowg = (long long)BCD_ROW_BC * 8;
     const long long strA = (long long)pstep * 2 * rowl, strL = (long long)pstep * rowl, strG = (long long)pstep * 2 * rowg;
     gptr_t pA = uniform_ptr((const char *)ps.pl.blkA + ((long long)pix0 * 2 + dir) * rowl);      // row of step `nextA`
     gptr_t pL = uniform_ptr((const char *)ps.pl.lab + (long long)pix0 * rowl);
-    gptr_t pB = uniform_ptr((const char *)ps.pl.blkB + ((long long)pix0 * 2 + dir) * rowg + (long long)wave * 512);   // row of step `nextG`
-    gptr_t pC = uniform_ptr((const char *)ps.pl.blkC + ((long long)pix0 * 2 + dir) * rowg + (long long)wave * 512);
+    // this wave's second blocks of step `nextG`; its third blocks lie coff bytes further
+    gptr_t pB = uniform_ptr((const char *)ps.pl.blkBC + ((long long)pix0 * 2 + dir) * rowg + (long long)wave * (BCD_CAP_B01 * 8));
+    const uint32_t coff = (uint32_t)(BCD_ROW_B * 8 + wave * (BCD_CAP_C01 * 8) - wave * (BCD_CAP_B01 * 8));
     int nextA = 0, nextG = 0;
     auto advA = [&]() { const bool m = nextA + 1 < len; pA += m ? strA : 0; pL += m ? strL : 0; nextA++; };
-    auto advG = [&]() { const bool m = nextG + 1 < len; pB += m ? strG : 0; pC += m ? strG : 0; nextG++; };
+    auto advG = [&]() { const bool m = nextG + 1 < len; pB += m ? strG : 0; nextG++; };
     auto ld8 = [](gptr_t base, uint32_t off) {
         const unsigned long long v = *reinterpret_cast<const __attribute__((address_space(1))) unsigned long long *>(base + off);
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
@@ -377,14 +415,15 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
     // second / third block of the step the (pB, pC) row pointers stand at, given that step's first block: lanes that own
     // none keep the empty block
     auto fetchBC = [&](const uint2 &blkA, uint2 &B, uint2 &C) {
-        const uint32_t cnt = blkA.y >> 28;
-        const unsigned long long mb = ballot64(cnt > BCD_BLK) & ownmask;
-        const bool hb = owner && cnt > BCD_BLK, hc = owner && cnt > 2 * BCD_BLK;
+        // the blocks that were stored are a prefix (in lane order) of the labels that own one: the rank among the stored
+        // ones is the slot
+        const bool hb = owner && (blkA.y & BLK_HAS_B) != 0u, hc = owner && (blkA.y & BLK_HAS_C) != 0u;
+        const unsigned long long mb = ballot64(hb);
         B = make_uint2(BLK_EMPTY_X, BLK_EMPTY_Y); C = make_uint2(BLK_EMPTY_X, BLK_EMPTY_Y);
         if (mb) {                                                     // wave-uniform
             if (hb) B = ld8(pB, lane_rank(mb) * 8u);
-            const unsigned long long mc = ballot64(cnt > 2 * BCD_BLK) & ownmask;
-            if (mc) { if (hc) C = ld8(pC, lane_rank(mc) * 8u); }
+            const unsigned long long mc = ballot64(hc);
+            if (mc) { if (hc) C = ld8(pB, coff + lane_rank(mc) * 8u); }
         }
         advG();
     };
@@ -494,28 +533,40 @@ __global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
 #pragma unroll
             for (int j = 0; j < BCD_BLK; j++) { a2[j] = ((j < 4 ? bx >> (8 * j) : by) & 0xFFu) << 3; d2[j] = *reinterpret_cast<const double *>(prev + a2[j]); }
             { double vb; uint32_t kb; block_min(d2, a2, by, vb, kb); node(bestv, besta, vb, kb); }
-            // third block (a quarter of the waves), rows beyond 15 members (2 % of the workgroup steps)
+            // third block (a quarter of the waves), labels marked "more" (2 % of the workgroup steps; their count field says 15)
             if (__builtin_expect((ballot64((ay >> 28) > 2 * BCD_BLK) & actmask) != 0ull, 0)) {
 #pragma unroll
                 for (int j = 0; j < BCD_BLK; j++) { a2[j] = ((j < 4 ? cx >> (8 * j) : cy) & 0xFFu) << 3; d2[j] = *reinterpret_cast<const double *>(prev + a2[j]); }
                 { double vc; uint32_t kc; block_min(d2, a2, cy, vc, kc); node(bestv, besta, vc, kc); }
-                const bool more = act && (ay & 0x800u) != 0u;
-                if (__builtin_expect(ballot64(more) != 0ull, 0)) {
-                    // denser rows still: those lanes fetch their 160-bit row and walk what is left behind the 15th list
-                    // member, four set bits per round; still increasing k, so strict '<' stands.  The predecessor's
-                    // flows come from its label data (this path is rare; everything it reads is L2-resident)
-                    const int k14 = (int)(cy & 0xFFu);
+                const bool more = act && (ay & BLK_MORE) != 0u;
+                const unsigned long long moremask = ballot64(more);
+                if (__builtin_expect(moremask != 0ull, 0)) {
+                    // members beyond the blocks this label was given (more than 15, or a second / third block that found no
+                    // slot): the label walks what is left of its 160-bit row behind the last member it has seen, four set
+                    // bits per round; still increasing k, so strict '<' stands.  The predecessor's flows come from its label
+                    // data (this path is rare; everything it reads is L2-resident).  A row that found no place in the pool is
+                    // rebuilt here from the predecessor's flows (the predicate of bcd_lists_kernel, one label at a time).
+                    const int klast = (int)(((ay & BLK_HAS_C) ? cy : (ay & BLK_HAS_B) ? by : ay) & 0xFFu);
                     const size_t cpix = (size_t)(pix0 + i * pstep), ppix = (size_t)(pix0 + (i - 1) * pstep);
-                    const uint32_t *mrow = g_masks + ((cpix * 2 + dir) * LP + tl) * BCD_MASK_WORDS;
                     const uint2 *plab = g_lab + ppix * LP;
                     unsigned long long w0 = 0, w1 = 0, w2 = 0;
                     if (more) {
-                        w0 = (unsigned long long)mrow[0] | ((unsigned long long)mrow[1] << 32);
-                        w1 = (unsigned long long)mrow[2] | ((unsigned long long)mrow[3] << 32);
-                        w2 = (unsigned long long)mrow[4];
-                        const int b = k14 & 63;
+                        const uint32_t mbase = reinterpret_cast<const uint32_t *>(g_bc + (cpix * 2 + dir) * BCD_ROW_BC + BCD_ROW_B + BCD_ROW_C)[wave];
+                        const uint32_t slot = mbase + lane_rank(moremask);
+                        if (slot < pool_rows) {
+                            const uint32_t *mrow = g_masks + (size_t)slot * BCD_MASK_WORDS;
+                            w0 = (unsigned long long)mrow[0] | ((unsigned long long)mrow[1] << 32);
+                            w1 = (unsigned long long)mrow[2] | ((unsigned long long)mrow[3] << 32);
+                            w2 = (unsigned long long)mrow[4];
+                        } else {
+                            for (int k = klast + 1; k < pn; k++) {
+                                const unsigned long long bit = flow_l1_biased(Fc, plab[k].x) < tpsi ? 1ull << (k & 63) : 0ull;
+                                if (k < 64) w0 |= bit; else if (k < 128) w1 |= bit; else w2 |= bit;
+                            }
+                        }
+                        const int b = klast & 63;
                         const unsigned long long keep = b == 63 ? 0ull : (~0ull << (b + 1));
-                        if (k14 < 64) w0 &= keep; else if (k14 < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
+                        if (klast < 64) w0 &= keep; else if (klast < 128) { w0 = 0; w1 &= keep; } else { w0 = 0; w1 = 0; w2 &= keep; }
                     }
                     int base = 0;
                     auto next_bit = [&](bool &valid) {
@@ -637,13 +688,18 @@ static size_t back_bytes(const dflow_params *p)
 
 static size_t lab_bytes(const dflow_params *p) { return align256((size_t)p->pich * p->picw * p->label_pitch * 8); }
 static size_t blka_bytes(const dflow_params *p) { return align256((size_t)p->pich * p->picw * 2 * p->label_pitch * 8); }
-static size_t blkg_bytes(const dflow_params *p) { return align256((size_t)p->pich * p->picw * 2 * (BCD_GROUPS * 64) * 8); }
-static size_t mask_bytes(const dflow_params *p)
+static size_t blkbc_bytes(const dflow_params *p) { return align256((size_t)p->pich * p->picw * 2 * BCD_ROW_BC * 8); }
+static uint32_t pool_rows_of(const dflow_params *p)
 {
-    return align256((size_t)p->pich * p->picw * 2 * p->label_pitch * BCD_MASK_WORDS * sizeof(uint32_t));
+    const size_t rows = (size_t)p->pich * p->picw * 2 * p->label_pitch / BCD_POOL_DIV;
+    return (uint32_t)(rows < 4096 ? 4096 : rows);
 }
+static size_t mask_bytes(const dflow_params *p) { return align256((size_t)pool_rows_of(p) * BCD_MASK_WORDS * sizeof(uint32_t)); }
 
-size_t bcd_ws_bytes(const dflow_params *p) { return back_bytes(p) + lab_bytes(p) + blka_bytes(p) + 2 * blkg_bytes(p) + mask_bytes(p); }
+size_t bcd_ws_bytes(const dflow_params *p)
+{
+    return back_bytes(p) + lab_bytes(p) + blka_bytes(p) + blkbc_bytes(p) + mask_bytes(p) + 256;
+}
 
 static BcdPlanes planes_of(const dflow_params *p, void *ws)
 {
@@ -652,9 +708,10 @@ static BcdPlanes planes_of(const dflow_params *p, void *ws)
     pl.back = (uint8_t *)w; w += back_bytes(p);
     pl.lab = (uint2 *)w; w += lab_bytes(p);
     pl.blkA = (uint2 *)w; w += blka_bytes(p);
-    pl.blkB = (uint2 *)w; w += blkg_bytes(p);
-    pl.blkC = (uint2 *)w; w += blkg_bytes(p);
-    pl.masks = (uint32_t *)w;
+    pl.blkBC = (uint2 *)w; w += blkbc_bytes(p);
+    pl.masks = (uint32_t *)w; w += mask_bytes(p);
+    pl.cursor = (uint32_t *)w;
+    pl.pool_rows = pool_rows_of(p);
     return pl;
 }
 
@@ -662,6 +719,8 @@ int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const f
                        hipStream_t s)
 {
     long long items = 2LL * p->pich * p->picw;
+    if (hipMemsetAsync(planes_of(p, ws).cursor, 0, 256, s) != hipSuccess)
+        return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_bcd_prepare");
     hipLaunchKernelGGL(bcd_lists_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p->pich, p->picw, p->label_pitch,
                        p->tpsi, proposals, lcosts, nprop, planes_of(p, ws));
     return dflow_check_launch("bcd_lists_kernel");

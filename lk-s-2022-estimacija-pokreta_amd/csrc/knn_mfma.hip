@@ -72,9 +72,11 @@ template <int V> struct KmC { static constexpr int value = V; };
 #endif
 #define KM_MAXNW ((KM_STAGE_INS + KM_WAVES - 1) / KM_WAVES)     // DMA instructions of a wave per chunk: KM_MAXNW or one fewer
 #define KM_SPC (2 * (KM_CHUNK / 32))                           // event stores of a wave per chunk in pass 2 (tiles x groups)
-#define KM_EVROWS 32            // event entries (tile, 16-bit row mask) per lane, group and candidate cell
+#define KM_EVROWS_MAX 32        // event entries (tile, 16-bit row mask) per lane, group and candidate cell (mean 2.7, 99 % <= 7; a list
+                                // that runs out is redone by knn_fix_kernel): 32, 24 or 16, the largest that keeps the kNN stage's
+                                // scratch below what the BCD stage needs anyway (km_evrows)
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
-#define KM_LIST_WORDS (2 * KM_EVROWS * 64)       // one event list: [group][entry][lane] uint32
+#define KM_LIST_WORDS(evrows) (2 * (evrows) * 64)       // one event list: [group][entry][lane] uint32
 #define KM_T 1.7263349e-4                        // t = 2^-12.5: split of the cross terms |y~_q||E_c|, |E_q||y_c| (see header)
 #define KM_ETA 7.62939453125e-6                  // eta = 2^-17: allowance for the f32 accumulation inside the matrix core
 #define KM_MEAN_SAMPLES 1024
@@ -82,6 +84,7 @@ template <int V> struct KmC { static constexpr int value = V; };
 struct KmGeom {
     Geom g;
     int LP, qwaves;             // qwaves = 64-query groups per cell (of the largest cell)
+    int evrows;                 // entries per lane of an event list
     float tphi;
 };
 
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, 
 struct KmScreen {
     const _Float16 *h1, *h2;       // prepared f16 rows
     const float2 *qs;              // (S_q, 0.5 |q|^2) per image-1 pixel
-    uint32_t *ev;                  // [list][2][KM_EVROWS][64]: (tile << 16) | row mask
+    uint32_t *ev;                  // [list][2][evrows][64]: (tile << 16) | row mask
     uint8_t *ev_cnt;               // [list][2][64]; 255 = overflow
 };
 
@@ -358,10 +361,11 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 
     float a5[2][5];
     int cnt[2] = {0, 0};
-    const uint32_t evoff[2] = {(uint32_t)lane * 4u, (uint32_t)lane * 4u + KM_EVROWS * 256u};
+    const int evrows = a.evrows;
+    const uint32_t evoff[2] = {(uint32_t)lane * 4u, (uint32_t)lane * 4u + (uint32_t)evrows * 256u};
     const size_t lid = list_id(a, qcell, qwave, wslot);
     // wave-uniform buffer resource over this list; entry (gq, row) of a lane at 4 lane + 256 (32 gq + row)
-    const __amdgpu_buffer_rsrc_t evrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ev + lid * KM_LIST_WORDS), 0, KM_LIST_WORDS * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t evrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ev + lid * KM_LIST_WORDS(a.evrows)), 0, KM_LIST_WORDS(a.evrows) * 4, 0x00020000);
 
 #pragma unroll
     for (int gq = 0; gq < 2; gq++)
@@ -396,9 +400,9 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         // entry = (tile << 16) | (~neg & 0xFFFF) = neg ^ ((tile << 16) | 0xFFFF).  Always one store instruction (the vmcnt
         // bookkeeping of the ring counts on it): lanes with a mask write entry cnt of their list, the others (95 %) an offset
         // beyond the buffer's range, which the hardware drops without any memory traffic (raw buffer store, range checked).
-        // Entry KM_EVROWS-1 is never valid: a list that reaches it is reported as overflowed.
+        // Entry evrows-1 is never valid: a list that reaches it is reported as overflowed.
         const bool has = neg != 0xFFFFu;
-        const uint32_t off = has ? evoff[gq] + ((uint32_t)min(cnt[gq], KM_EVROWS - 1) << 8) : 0xFFFFFF00u;
+        const uint32_t off = has ? evoff[gq] + ((uint32_t)min(cnt[gq], evrows - 1) << 8) : 0xFFFFFF00u;
         __builtin_amdgcn_raw_buffer_store_b32(neg ^ (((uint32_t)tileidx << 16) | 0xFFFFu), evrsrc, (int)off, 0, 0);
         cnt[gq] += has ? 1 : 0;
     };
@@ -513,7 +517,7 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     }
     if (!wave_active) return;
 #pragma unroll
-    for (int gq = 0; gq < 2; gq++) p.ev_cnt[lid * 128 + gq * 64 + lane] = (uint8_t)(cnt[gq] >= KM_EVROWS ? 255 : cnt[gq]);
+    for (int gq = 0; gq < 2; gq++) p.ev_cnt[lid * 128 + gq * 64 + lane] = (uint8_t)(cnt[gq] >= evrows ? 255 : cnt[gq]);
 }
 
 // ------------------------------------------------------------------------------------------------ resolve
@@ -631,7 +635,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
     auto prefetch = [&](int cj) {
         const size_t lid = list_id(a, qcell, qwave, (ci - cimin) * nrows + (cj - cjmin));
         nA_n = p.ev_cnt[lid * 128 + gq * 64 + col]; nB_n = p.ev_cnt[lid * 128 + gq * 64 + col + 32];
-        const uint32_t *ev = p.ev + lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + col;
+        const uint32_t *ev = p.ev + lid * KM_LIST_WORDS(a.evrows) + (size_t)gq * a.evrows * 64 + col;
 #pragma unroll
         for (int e = 0; e < 4; e++) { entA_n[e] = ev[e * 64]; entB_n[e] = ev[e * 64 + 32]; }     // entries past the count are ignored below
     };
@@ -643,7 +647,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
         const int ntiles = (ccw * (g.y1(cj) - cy0) + KM_CHUNK - 1) / KM_CHUNK * (KM_CHUNK / 32);   // as in the screen kernel
         const int nA = nA_n, nB = nB_n;
         bool ovf = nA == 255 || nB == 255;
-        const uint32_t *evA = p.ev + (size_t)lid * KM_LIST_WORDS + (size_t)gq * KM_EVROWS * 64 + col;
+        const uint32_t *evA = p.ev + (size_t)lid * KM_LIST_WORDS(a.evrows) + (size_t)gq * a.evrows * 64 + col;
         uint32_t entA[4], entB[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) { entA[e] = e < nA && !ovf ? entA_n[e] : 0u; entB[e] = e < nB && !ovf ? entB_n[e] : 0u; }
@@ -789,14 +793,26 @@ static size_t num_lists(const dflow_params *p)
 
 #define KM_OVF_CAP 8192
 
-size_t knn_mfma_ws_bytes(const dflow_params *p)
+static size_t knn_mfma_ws_bytes_for(const dflow_params *p, int evrows)
 {
     size_t N = (size_t)p->pich * p->picw;
     size_t nl = num_lists(p);
     return (N + km_total_rows(make_geom(p))) * KM_K * sizeof(_Float16) + N * sizeof(float2) + 1024 +
            DFLOW_DESC * DFLOW_DESC * sizeof(double) + knn_pca_ws_bytes() + 512 +
-           KM_OVF_CAP * sizeof(int4) + nl * (KM_LIST_WORDS * sizeof(uint32_t) + 128) + 1024;
+           KM_OVF_CAP * sizeof(int4) + nl * (KM_LIST_WORDS(evrows) * sizeof(uint32_t) + 128) + 1024;
 }
+
+// entries per lane of the event lists: as many as fit below the scratch of the BCD stage (the workspace is one buffer for
+// all stages, so the lists then cost nothing), at least 16
+static int km_evrows(const dflow_params *p)
+{
+    const size_t budget = bcd_ws_bytes(p);
+    for (int e = KM_EVROWS_MAX; e > 16; e -= 8)
+        if (knn_mfma_ws_bytes_for(p, e) <= budget) return e;
+    return 16;
+}
+
+size_t knn_mfma_ws_bytes(const dflow_params *p) { return knn_mfma_ws_bytes_for(p, km_evrows(p)); }
 
 bool knn_mfma_supported(const dflow_params *p)
 {
@@ -827,7 +843,8 @@ int launch_knn_mfma(const dflow_params *p, const void *d1, const void *d2, uint3
     void *pca_ws = w; w += knn_pca_ws_bytes();
     int4 *ovf = (int4 *)w; w += KM_OVF_CAP * sizeof(int4);
     w = align256(w);
-    uint32_t *ev = (uint32_t *)w; w += nl * KM_LIST_WORDS * sizeof(uint32_t);
+    const int evrows = km_evrows(p);
+    uint32_t *ev = (uint32_t *)w; w += nl * KM_LIST_WORDS(evrows) * sizeof(uint32_t);
     uint8_t *ev_cnt = (uint8_t *)w;
     if (hipMemsetAsync(ctr, 0, 256, s) != hipSuccess)
         return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_knn_mfma");
@@ -852,6 +869,7 @@ int launch_knn_mfma(const dflow_params *p, const void *d1, const void *d2, uint3
     KmGeom a;
     a.g = g; a.LP = p->label_pitch; a.tphi = p->tphi;
     a.qwaves = (max_cell_points(g) + KM_QPW - 1) / KM_QPW;
+    a.evrows = evrows;
     int win = 2 * g.win + 1;
     int wgs_per_cell = (win * win * a.qwaves + KM_WAVES - 1) / KM_WAVES;
     KmScreen sc;

@@ -32,3 +32,9 @@ for name, (oy, ox) in (("dir0 (vertical)", (1, 0)), ("dir1 (horizontal)", (0, 1)
         print("  wave %d: max-count mean %.2f " % (wv, mx.mean()) + " ".join("any>%d: %.3f" % (t, (mx > t).mean()) for t in (5, 8, 10, 12, 15, 16, 20)))
     mx = c.amax(-1).cpu().numpy().ravel()
     print("  block: " + " ".join("any>%d: %.3f" % (t, (mx > t).mean()) for t in (5, 8, 10, 12, 15, 16, 20)))
+    # owners of a second (> 5 members) / third (> 10) block per 64-label wave: how often do BCD_CAP_B / BCD_CAP_C slots not suffice?
+    for wv in range(3):
+        nb = (c[..., 64 * wv:64 * wv + 64] > 5).sum(-1).cpu().numpy().ravel(); nc = (c[..., 64 * wv:64 * wv + 64] > 10).sum(-1).cpu().numpy().ravel()
+        nm = (c[..., 64 * wv:64 * wv + 64] > 15).sum(-1).cpu().numpy().ravel()
+        print("  wave %d owners: B mean %.1f " % (wv, nb.mean()) + " ".join(">%d: %.4f" % (t, (nb > t).mean()) for t in (24, 32, 40, 48, 56)) +
+              " | C mean %.2f " % nc.mean() + " ".join(">%d: %.4f" % (t, (nc > t).mean()) for t in (4, 8, 12, 16, 24, 32)) + " | any>15: %.4f" % (nm > 0).mean())
