@@ -177,12 +177,20 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
         // longest list): |dy-dy'| + |dx-dx'| against the member's flow; empty slots (0xFF) read a valid word and are zeroed
         uint32_t p0 = 0u, p1 = 0u;
         if (64 * grp < tn) {
+            auto slots = [&](auto lo, auto hi) {
 #pragma unroll
-            for (int e = 0; e < BCD_LIST; e++) {
-                const uint32_t word = e < 4 ? l0 : (e < 8 ? l1 : (e < 12 ? l2 : l3));
-                const uint32_t k = (word >> (8 * (e & 3))) & 0xFFu;
-                const uint32_t psi = e < n ? flow_l1_biased(me, s_cols[wv][min(k, 191u)]) : 0u;    // k < 160, or 0xFF (empty slot) -> 191: inside the row
-                if (e < 8) p0 |= psi << (4 * e); else p1 |= psi << (4 * (e - 8));
+                for (int e = decltype(lo)::value; e < decltype(hi)::value; e++) {
+                    const uint32_t word = e < 4 ? l0 : (e < 8 ? l1 : (e < 12 ? l2 : l3));
+                    const uint32_t k = (word >> (8 * (e & 3))) & 0xFFu;
+                    const uint32_t psi = e < n ? flow_l1_biased(me, s_cols[wv][min(k, 191u)]) : 0u;    // k < 160, or 0xFF (empty slot) -> 191: inside the row
+                    if (e < 8) p0 |= psi << (4 * e); else p1 |= psi << (4 * (e - 8));
+                }
+            };
+            // slots 5..9 / 10..14 only if some label of the wave has that many members (wave-uniform: 97 % / 25 % of the waves)
+            slots(BcdC<0>(), BcdC<BCD_BLK>());
+            if (__ballot(n > BCD_BLK)) {
+                slots(BcdC<BCD_BLK>(), BcdC<2 * BCD_BLK>());
+                if (__ballot(n > 2 * BCD_BLK)) slots(BcdC<2 * BCD_BLK>(), BcdC<BCD_LIST>());
             }
         }
         // bytes 0..3 | 4, 5..8 | 9, 10..13 | 14 and nibbles 0..4, 5..9, 10..14 -> the three blocks

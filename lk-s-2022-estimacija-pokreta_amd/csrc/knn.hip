@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, co
 // distances stay in index order), so the result is that of one sequential scan.  A single overflowed list used to cost
 // the latency of one wave walking a whole cell (1.3 ms at 64x27 cells); split over 16 waves it costs 0.1 ms.
 #define KNN_FIX_WAVES 16
+#define KNN_FIX_BLOCKS 256            // one per CU: a launch that finds no item costs 4 096 wave starts (1 024 blocks: 16 384, which
+                                  // delayed the stream by a millisecond when other kernels held the CUs)
 __device__ static inline void top5_insert(Top5 &t, float cd, int cidx)
 {
     bool sh = false;
@@ -258,10 +260,10 @@ int launch_knn_fix(const dflow_params *p, const void *d1, const void *d2, uint32
     int maxpts = (a.g.x1(a.g.ncx - 1) - a.g.x0(a.g.ncx - 1)) * (a.g.y1(a.g.ncy - 1) - a.g.y0(a.g.ncy - 1));
     int qwaves = (maxpts + 63) / 64;
     if (descr_f16(p))
-        hipLaunchKernelGGL(knn_fix_kernel<_Float16>, dim3(1024), dim3(64 * KNN_FIX_WAVES), 0, s, a, (const _Float16 *)d1, (const _Float16 *)d2, proposals,
+        hipLaunchKernelGGL(knn_fix_kernel<_Float16>, dim3(KNN_FIX_BLOCKS), dim3(64 * KNN_FIX_WAVES), 0, s, a, (const _Float16 *)d1, (const _Float16 *)d2, proposals,
                            lcosts, ovf_count, ovf_list, ovf_cap, flags, qwaves);
     else
-        hipLaunchKernelGGL(knn_fix_kernel<float>, dim3(1024), dim3(64 * KNN_FIX_WAVES), 0, s, a, (const float *)d1, (const float *)d2, proposals,
+        hipLaunchKernelGGL(knn_fix_kernel<float>, dim3(KNN_FIX_BLOCKS), dim3(64 * KNN_FIX_WAVES), 0, s, a, (const float *)d1, (const float *)d2, proposals,
                            lcosts, ovf_count, ovf_list, ovf_cap, flags, qwaves);
     return dflow_check_launch("knn_fix_kernel");
 }
