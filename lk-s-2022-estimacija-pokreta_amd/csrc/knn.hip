@@ -142,11 +142,14 @@ __global__ void __launch_bounds__(KNN_THREADS, 4) knn_exact_kernel(KnnArgs a, co
 // Fix-up for the MFMA path.  Work item = (query cell, first query index, 64 queries, candidate cell).  Items come
 // from the overflow list, or -- if the prep kernel flagged out-of-range descriptors or the list itself overflowed --
 // every item of the pass is enumerated.  A workgroup of KNN_FIX_WAVES waves takes one item at a time (grid-stride): all
-// waves hold the same 64 queries (lane = query), wave w scans every KNN_FIX_WAVES-th ROW of the candidate cell, the partial
-// top-5 lists meet in LDS and wave 0 merges them in row order with the insertion rule of the scan (strict '<': equal
-// distances stay in index order), so the result is that of one sequential scan.  A single overflowed list used to cost
-// the latency of one wave walking a whole cell (1.3 ms at 64x27 cells); split over 16 waves it costs 0.1 ms.
+// waves hold the same 64 queries (lane = query); the candidate cell streams through LDS in chunks of KNN_FIX_CHUNK rows that
+// all threads fetch together (one 16-byte piece per thread, the next chunk's loads in flight while this one is evaluated);
+// wave w evaluates candidates w, w + 16 of every chunk (broadcast LDS reads), the partial top-5 lists meet in LDS and wave
+// 0 merges them by (distance, index), so the result is that of one sequential scan.  A single overflowed list used to
+// cost the latency of one wave walking a whole cell through the scalar cache (1.3 ms at 64x27 cells; 0.34 ms with the
+// rows dealt to 16 waves: about 2 us per candidate, all of it load latency).
 #define KNN_FIX_WAVES 16
+#define KNN_FIX_CHUNK 64              // candidates per LDS chunk (four per wave)
 #define KNN_FIX_BLOCKS 256            // one per CU: a launch that finds no item costs 4 096 wave starts (1 024 blocks: 16 384, which
                                   // delayed the stream by a millisecond when other kernels held the CUs)
 __device__ static inline void top5_insert(Top5 &t, float cd, int cidx)
@@ -165,6 +168,7 @@ __global__ void __launch_bounds__(64 * KNN_FIX_WAVES) knn_fix_kernel(KnnArgs a, 
 {
     __shared__ float pd[KNN_FIX_WAVES][5][64];
     __shared__ int pi[KNN_FIX_WAVES][5][64];
+    __shared__ __attribute__((aligned(16))) float cand[2][KNN_FIX_CHUNK][DFLOW_DESC_PITCH_H];      // rows widened to float32
     const Geom g = a.g;
     const int win = 2 * g.win + 1;
     const int nov = *ovf_count;
@@ -199,17 +203,65 @@ __global__ void __launch_bounds__(64 * KNN_FIX_WAVES) knn_fix_kernel(KnnArgs a, 
         float q[DFLOW_DESC];
         desc_load_row(q, gd1, pix);
         constexpr int P = DescPitch<T>::value;
-        // ---- this wave's rows of the candidate cell
-        const int cx0 = g.x0(ci), cy0 = g.y0(cj), cy1 = g.y1(cj), ccw = g.x1(ci) - cx0;
+        // ---- the candidate cell, chunk by chunk through LDS
+        const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0, cnpts = ccw * (g.y1(cj) - cy0);
+        const int nchunks = (cnpts + KNN_FIX_CHUNK - 1) / KNN_FIX_CHUNK;
+        constexpr int PIECES = P * (int)sizeof(T) / 16;                   // 16-byte pieces per row: 17 (float32) or 9 (binary16)
+        constexpr int NPC = (KNN_FIX_CHUNK * PIECES + 64 * KNN_FIX_WAVES - 1) / (64 * KNN_FIX_WAVES);   // pieces of a chunk per thread
+        uint4 piece[NPC];
+#pragma unroll
+        for (int u = 0; u < NPC; u++) piece[u] = make_uint4(0u, 0u, 0u, 0u);
+        auto fetch = [&](int chunk) {
+#pragma unroll
+            for (int u = 0; u < NPC; u++) {
+                const int tp = (int)threadIdx.x + u * 64 * KNN_FIX_WAVES, idx = chunk * KNN_FIX_CHUNK + tp / PIECES;
+                if (tp < KNN_FIX_CHUNK * PIECES && idx < cnpts)
+                    piece[u] = reinterpret_cast<const uint4 *>(gd2 + ((size_t)(cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * P)[tp % PIECES];
+            }
+        };
+        auto deposit = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < NPC; u++) {
+                const int tp = (int)threadIdx.x + u * 64 * KNN_FIX_WAVES, lj = tp / PIECES, lpc = tp % PIECES;
+                if (tp >= KNN_FIX_CHUNK * PIECES) continue;
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<uint4 *>(&cand[buf][lj][4 * lpc]) = piece[u];
+                } else {
+                    const dflow_h8 v = __builtin_bit_cast(dflow_h8, piece[u]);
+                    float4 lo = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]), hi = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+                    *reinterpret_cast<float4 *>(&cand[buf][lj][8 * lpc]) = lo;
+                    if (8 * lpc + 4 < DFLOW_DESC_PITCH_H) *reinterpret_cast<float4 *>(&cand[buf][lj][8 * lpc + 4]) = hi;
+                }
+            }
+        };
         Top5 t;
         t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
         t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
-        for (int yy = cy0 + wave; yy < cy1; yy += KNN_FIX_WAVES) {
-            const T *__restrict__ row = gd2 + ((size_t)yy * g.W + cx0) * P;
-            for (int xx = 0; xx < ccw; xx++) {
-                const float acc = canon_dist(q, row + (size_t)xx * P);   // wave-uniform address
-                if (acc < t.d4) top5_insert(t, acc, (yy - cy0) * ccw + xx);
+        fetch(0);
+        deposit(0);
+        __syncthreads();
+        for (int chunk = 0; chunk < nchunks; chunk++) {
+            if (chunk + 1 < nchunks) fetch(chunk + 1);
+#pragma unroll
+            for (int jj = 0; jj < KNN_FIX_CHUNK / KNN_FIX_WAVES; jj++) {
+                const int j = wave + jj * KNN_FIX_WAVES, idx = chunk * KNN_FIX_CHUNK + j;      // increasing within a wave
+                if (idx < cnpts) {                                                             // wave-uniform
+                    const float4 *c4 = reinterpret_cast<const float4 *>(cand[chunk & 1][j]);
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < DFLOW_DESC / 4; k++) {
+                        const float4 v = c4[k];
+                        float e;
+                        e = q[4 * k] - v.x; acc = __fmaf_rn(e, e, acc);
+                        e = q[4 * k + 1] - v.y; acc = __fmaf_rn(e, e, acc);
+                        e = q[4 * k + 2] - v.z; acc = __fmaf_rn(e, e, acc);
+                        e = q[4 * k + 3] - v.w; acc = __fmaf_rn(e, e, acc);
+                    }
+                    if (acc < t.d4) top5_insert(t, acc, idx);
+                }
             }
+            if (chunk + 1 < nchunks) deposit((chunk + 1) & 1);
+            __syncthreads();
         }
         pd[wave][0][lane] = t.d0; pd[wave][1][lane] = t.d1; pd[wave][2][lane] = t.d2; pd[wave][3][lane] = t.d3; pd[wave][4][lane] = t.d4;
         pi[wave][0][lane] = t.i0; pi[wave][1][lane] = t.i1; pi[wave][2][lane] = t.i2; pi[wave][3][lane] = t.i3; pi[wave][4][lane] = t.i4;

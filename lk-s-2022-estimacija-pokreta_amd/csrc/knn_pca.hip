@@ -37,9 +37,10 @@ __global__ void __launch_bounds__(256) knn_cov_kernel(const T *__restrict__ d, c
     __syncthreads();
     for (int e = threadIdx.x; e < PCA_N * PCA_N; e += 256) {
         const int i = e / PCA_N, j = e % PCA_N;
-        double acc = 0.0;
-        for (int sl = 0; sl < PCA_BLOCK_SAMPLES; sl++) acc = fma((double)xs[sl][i], (double)xs[sl][j], acc);
-        partial[(size_t)blockIdx.x * PCA_N * PCA_N + e] = acc;
+        // float32 inside a block (256 terms: 1e-5 relative, the matrix only steers the choice of the basis), float64 across blocks
+        float acc = 0.0f;
+        for (int sl = 0; sl < PCA_BLOCK_SAMPLES; sl++) acc = fmaf(xs[sl][i], xs[sl][j], acc);
+        partial[(size_t)blockIdx.x * PCA_N * PCA_N + e] = (double)acc;
     }
 }
 
