@@ -17,7 +17,7 @@ int main()
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 5; rep++) {
         hipEventRecord(e0, 0);
-        launch_knn_pca(dd, mu, vt, flags, ws, npix, 0);
+        launch_knn_pca(dd, false, mu, vt, flags, ws, npix, 0);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         int f; hipMemcpy(&f, flags, 4, hipMemcpyDeviceToHost);
