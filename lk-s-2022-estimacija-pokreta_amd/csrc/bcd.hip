@@ -26,6 +26,9 @@
 #include "dflow_common.h"
 
 #define BCD_THREADS 192
+#ifndef BCD_MINWAVES
+#define BCD_MINWAVES 5                   // waves per SIMD the chain kernel is compiled for (96 VGPRs: six workgroups per CU)
+#endif
 #define BCD_MASK_WORDS 5                 // 160 bits per label row (kept in HBM only for rows with more than 15 members)
 #define BCD_BLK 5                        // list members per 8-byte block
 #define BCD_LIST 15                      // members carried by blocks (3 blocks); longer rows continue in their bit row
@@ -350,7 +353,7 @@ __device__ static inline gptr_t uniform_ptr(const void *p)
 }
 __device__ static inline unsigned long long ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
-__global__ void __launch_bounds__(BCD_THREADS, 5) bcd_chain_kernel(BcdArgs a)
+__global__ void __launch_bounds__(BCD_THREADS, BCD_MINWAVES) bcd_chain_kernel(BcdArgs a)
 {
     // static LDS has compile-time addresses, so the offsets fold into the ds_read immediates
     __shared__ double s_dp[2 * BCD_LDS_LABELS];                               // [2][labels]; entries >= 160 stay +inf (list sentinel 0xFF)
