@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(1024) knn_jacobi_kernel(const double *__restri
     for (int t = tid; t < NT; t += 1024) {
         const int a = t / (PCA_N / 4), b4 = (t % (PCA_N / 4)) * 4;
         double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
-        for (int i = 0; i < PCA_N; i++) {
+#pragma unroll 4
+        for (int i = 0; i < PCA_N; i++) {          // (fully unrolled the compiler hoists all 204 loads and spills)
             const double va = Vd[i][a];
             const double2 x01 = *reinterpret_cast<const double2 *>(&Vd[i][b4]), x23 = *reinterpret_cast<const double2 *>(&Vd[i][b4 + 2]);
             g0 = fma(va, x01.x, g0); g1 = fma(va, x01.y, g1); g2 = fma(va, x23.x, g2); g3 = fma(va, x23.y, g3);
@@ -164,6 +165,7 @@ __global__ void __launch_bounds__(1024) knn_jacobi_kernel(const double *__restri
         double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
         if (t < NT) {
             const int i = t / (PCA_N / 4), j4 = (t % (PCA_N / 4)) * 4;
+#pragma unroll 4
             for (int k = 0; k < PCA_N; k++) {
                 const double v = Vd[i][k];
                 const double2 x01 = *reinterpret_cast<const double2 *>(&G[k][j4]), x23 = *reinterpret_cast<const double2 *>(&G[k][j4 + 2]);
@@ -196,7 +198,8 @@ __global__ void __launch_bounds__(1024) knn_jacobi_kernel(const double *__restri
     for (int t = tid; t < NT; t += 1024) {
         const int a = t / (PCA_N / 4), b4 = (t % (PCA_N / 4)) * 4;
         double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
-        for (int i = 0; i < PCA_N; i++) {
+#pragma unroll 4
+        for (int i = 0; i < PCA_N; i++) {          // (fully unrolled the compiler hoists all 204 loads and spills)
             const double va = Vd[i][a];
             const double2 x01 = *reinterpret_cast<const double2 *>(&Vd[i][b4]), x23 = *reinterpret_cast<const double2 *>(&Vd[i][b4 + 2]);
             g0 = fma(va, x01.x, g0); g1 = fma(va, x01.y, g1); g2 = fma(va, x23.x, g2); g3 = fma(va, x23.y, g3);
