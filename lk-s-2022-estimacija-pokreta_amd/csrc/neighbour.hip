@@ -54,13 +54,28 @@ __device__ static inline void py_slice(int start, int stop, int n, int &lo, int 
     lo = start; hi = stop > start ? stop : start;
 }
 
+// tv "in" proposals[lo:hi] (either component equal, Q5).  The slice holds at most K = 5 entries (one cell's 5-pack): all of them
+// are fetched at once -- a loop with an early exit makes every load wait for the comparison before it, up to five dependent
+// round trips per draw, which was most of this kernel's time -- and compared afterwards; slots beyond the slice read the
+// row's first entry (always inside the row) and are ignored.
+#define NBR_MAXK 5
 __device__ static inline bool tv_in(const uint32_t *prow, int lo, int hi, uint32_t tv)
 {
-    for (int i = lo; i < hi; i++) {
-        uint32_t v = prow[i];
-        if ((v & 0xFFFFu) == (tv & 0xFFFFu) || (v >> 16) == (tv >> 16)) return true;   // either component equal (Q5)
+    if (hi - lo > NBR_MAXK) {               // other K: the plain loop
+        for (int i = lo; i < hi; i++) {
+            uint32_t v = prow[i];
+            if ((v & 0xFFFFu) == (tv & 0xFFFFu) || (v >> 16) == (tv >> 16)) return true;
+        }
+        return false;
     }
-    return false;
+    uint32_t v[NBR_MAXK];
+#pragma unroll
+    for (int j = 0; j < NBR_MAXK; j++) v[j] = prow[lo + j < hi ? lo + j : 0];
+    bool in = false;
+#pragma unroll
+    for (int j = 0; j < NBR_MAXK; j++)
+        in |= lo + j < hi && ((v[j] & 0xFFFFu) == (tv & 0xFFFFu) || (v[j] >> 16) == (tv >> 16));
+    return in;
 }
 
 #define NBR_THREADS 128
@@ -103,14 +118,20 @@ template <typename T> __global__ void __launch_bounds__(NBR_THREADS) neighbour_k
         const int broj = a.K * ((g.celly(tgy) - mincellyl) + (g.cellx(tgx) - mincellxl) * ncellyl);   // :223-224
         const int tpix = tgy * g.W + tgx;
         const uint32_t tv = a.bestflow[tpix];                                                           // :225
+
         int lo, hi, lo2, hi2;
         py_slice(broj, broj + a.K, a.L, lo, hi);
         py_slice(np_ - ngp, np_, a.L, lo2, hi2);
         // the second slice is exactly what this thread appended (np_ <= L and ngp <= np_ always): kept in LDS
         bool dup = tv_in(prow, lo, hi, tv);                                 // :226
-        for (int j = lo2 - (np_ - ngp); !dup && j < hi2 - (np_ - ngp); j++) {
-            const uint32_t v = s_app[j * NBR_THREADS + threadIdx.x];
-            dup = (v & 0xFFFFu) == (tv & 0xFFFFu) || (v >> 16) == (tv >> 16);
+        // eight entries of the LDS slice per round, fetched together (same reason as in tv_in)
+        const int j1 = hi2 - (np_ - ngp);
+        for (int j0 = lo2 - (np_ - ngp); j0 < j1; j0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = s_app[(j0 + u < j1 ? j0 + u : j0) * NBR_THREADS + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < 8; u++) dup |= j0 + u < j1 && ((v[u] & 0xFFFFu) == (tv & 0xFFFFu) || (v[u] >> 16) == (tv >> 16));
         }
         if (!dup) {
             prow[np_] = tv;                                                 // :227
