@@ -760,7 +760,12 @@ __global__ void __launch_bounds__(256) knn_finalize_kernel(Geom g, int LP, uint3
     const int n = 5 * wy * wx;
     const float *lc = lcosts + (size_t)px * LP;
     float mind = 1000.0f; int best = 0x7fffffff;
-    for (int l = sub; l < n; l += 16) { const float c = lc[l]; if (c < mind) { mind = c; best = l; } }
+    // all of a lane's costs are fetched before the first comparison (a rolled loop waits for every load in turn)
+    float cs[DFLOW_MAX_LABELS / 16];
+#pragma unroll
+    for (int j = 0; j < DFLOW_MAX_LABELS / 16; j++) cs[j] = sub + 16 * j < n ? lc[sub + 16 * j] : 1000.0f;
+#pragma unroll
+    for (int j = 0; j < DFLOW_MAX_LABELS / 16; j++) if (cs[j] < mind) { mind = cs[j]; best = sub + 16 * j; }
 #pragma unroll
     for (int sh = 1; sh < 16; sh <<= 1) {       // row_shl 1,2,4,8: lane 0 of every 16-lane row ends with the row minimum
         const int ctrl = 0x100 + sh;

@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256) knn_cov_kernel(const T *__restrict__ d, c
         const int i = e / PCA_N, j = e % PCA_N;
         // float32 inside a block (256 terms: 1e-5 relative, the matrix only steers the choice of the basis), float64 across blocks
         float acc = 0.0f;
+#pragma unroll 16
         for (int sl = 0; sl < PCA_BLOCK_SAMPLES; sl++) acc = fmaf(xs[sl][i], xs[sl][j], acc);
         partial[(size_t)blockIdx.x * PCA_N * PCA_N + e] = (double)acc;
     }
