@@ -589,6 +589,7 @@ __device__ static inline void key_insert(unsigned long long (&k)[5], float (&c)[
 // by the same (distance, index) keys, so the results are identical.
 #define KM_EVLIST2 30            // candidates per query and candidate cell listed in LDS at a time (more: further passes);
                                  // 30: stage + lists + offsets = 20 KB per wave = 8 waves per CU
+typedef float km_f2 __attribute__((ext_vector_type(2)));
 template <bool F16>
 __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve p)
 {
@@ -709,7 +710,10 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
 #pragma unroll
                 for (int k = 0; k < 17; k++) {
                     const float4 v = cv[k];
-                    const float e0 = q[4 * k] - v.x, e1 = q[4 * k + 1] - v.y, e2 = q[4 * k + 2] - v.z, e3 = q[4 * k + 3] - v.w;
+                    // two differences per instruction (v_pk_add_f32 with negated operand: the same IEEE subtraction per half)
+                    const km_f2 ea = (km_f2){q[4 * k], q[4 * k + 1]} - (km_f2){v.x, v.y};
+                    const km_f2 eb = (km_f2){q[4 * k + 2], q[4 * k + 3]} - (km_f2){v.z, v.w};
+                    const float e0 = ea.x, e1 = ea.y, e2 = eb.x, e3 = eb.y;
                     acc = __fmaf_rn(e0, e0, acc); acc = __fmaf_rn(e1, e1, acc);
                     acc = __fmaf_rn(e2, e2, acc); acc = __fmaf_rn(e3, e3, acc);
                     const int j = (4 * k) & 7;
