@@ -318,6 +318,39 @@ def test_kitti_config5_as_stated_matches_oracle(torch_, oracle, synth):
         O.set_threads(1)
 
 
+def test_full_hd_frame_matches_oracle(torch_, oracle, synth):
+    """The largest frame the design is sized for (1920x1080 in 13.7 GB of workspace), cells of 30x40 px (the
+    bench's 64x27 grid): every stage of the whole frame against the oracle -- proposals / costs / counts / labels after
+    generisi and after nasumicni, labels after each of 2 sweeps.  The reference hard-codes 1241x375 (daisy i flann.py:34-35);
+    SURVEY Q12 asks the build to generalise, the oracle defines the result."""
+    H, W, ch, cw = 1080, 1920, 40, 30
+    O = oracle
+    O.set_threads(16)
+    try:
+        img1, img2, _ = synth.make_pair(H, W, seed=1080)
+        df = make(H, W, ch, cw, seed=11)
+        assert df.ws_bytes < 15 * 2 ** 30
+        p = oracle_params(O, df)
+        df.load_pair(img1, img2)
+        d1, d2 = O.daisy(img1), O.daisy(img2)
+        df.generisi()
+        pr, lc, npr, bl = O.knn_proposals(p, d1, d2)
+        st = df.host_state()
+        assert np.array_equal(st["nprop"], npr) and np.array_equal(st["proposals"], pr)
+        assert np.array_equal(st["lcosts"], lc) and np.array_equal(st["bestlabels"], bl)
+        df.nasumicni()
+        O.neighbour_proposals(p, d1, d2, pr, lc, npr, bl)
+        st = df.host_state()
+        assert np.array_equal(st["nprop"], npr) and np.array_equal(st["proposals"], pr) and np.array_equal(st["lcosts"], lc)
+        del st
+        for w in range(2):
+            df.ceoBCD(1)
+            O.bcd_sweep(p, pr, lc, npr, bl)
+            assert np.array_equal(df.bestlabels.cpu().numpy(), bl), "sweep %d" % (w + 1)
+    finally:
+        O.set_threads(1)
+
+
 @pytest.mark.parametrize("geom", [(375, 1241, 25, 73), (375, 1242, 25, 54)])
 def test_kitti_geometries_sampled(torch_, oracle, synth, geom):
     """BASELINE configs 1 and 5 geometries (daisy i flann.py:34-43, discrete_flow.py:22-31): invariants, sampled exact
