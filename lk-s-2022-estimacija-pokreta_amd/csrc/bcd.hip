@@ -82,89 +82,116 @@ struct BcdPlanes {
 template <int V> struct BcdC { static constexpr int value = V; };
 
 // ------------------------------------------------------------------------------------------------ lists
-// grid: one wave per (pixel, dir); dir 0 = the pixel's column chain, dir 1 = its row chain.
+// grid: one wave per pixel q, as the PREDECESSOR: q's labels are the wave-uniform side of the tests for both pixels that
+// have q in front of them -- its successor on the column chain (dir 0) and on the row chain (dir 1) -- so the scalar loads
+// of q's row are shared, and the labels 128..159 of the two successors (22 of 32 in use) share ONE group of 64 lanes:
+// 5 lane groups for 300 labels where one wave per (pixel, direction) had 6.  (The bench responds to this kernel's VALU
+// count one to one)  A pixel that starts a chain has no predecessor: its empty rows are written by its own wave.
 __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, int tpsi, const uint32_t *__restrict__ proposals,
                                                         const float *__restrict__ lcosts, const int32_t *__restrict__ nprop,
                                                         BcdPlanes pl)
 {
-    __shared__ uint32_t s_cols[4][192];                      // the predecessor's biased labels, per wave
+    __shared__ uint32_t s_cols[4][192];                      // q's biased labels, per wave
     __shared__ __attribute__((aligned(16))) uint8_t s_list[4][64][16];   // member lists being built, per wave and lane
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long item = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv);
-    if (item >= 2LL * H * W) return;
-    const int dir = (int)(item & 1);
-    const int pix = (int)(item >> 1);
-    const int y = pix / W, x = pix % W;
-    // predecessor on the chain (python bcd.py:265-277): even columns run down, odd columns up, even rows leftwards, odd rows rightwards
-    int py = y, px = x;
-    if (dir == 0) py = (x & 1) ? y + 1 : y - 1; else px = (y & 1) ? x - 1 : x + 1;
-    const bool start = py < 0 || py >= H || px < 0 || px >= W;     // chain start: no transition into this pixel
-    const int ppix = start ? pix : py * W + px;
-    const int tn = nprop[pix], pn = start ? 0 : nprop[ppix];
-    uint32_t fp[3], fcv[3];
+    const int q = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv);
+    if (q >= H * W) return;
+    const int y = q / W, x = q % W;
+    // predecessors on the chains (python bcd.py:265-277): even columns run down, odd columns up, even rows leftwards, odd
+    // rows rightwards; the successors lie on the other side
+    const int py = (x & 1) ? y + 1 : y - 1, sy = (x & 1) ? y - 1 : y + 1;
+    const int px = (y & 1) ? x - 1 : x + 1, sx = (y & 1) ? x + 1 : x - 1;
+    const bool start0 = py < 0 || py >= H, start1 = px < 0 || px >= W;      // q starts its column / row chain
+    const bool v0 = sy >= 0 && sy < H, v1 = sx >= 0 && sx < W;              // q has a successor on its column / row chain
+    const int p0 = v0 ? sy * W + x : q, p1 = v1 ? y * W + sx : q;
+    const int pn = nprop[q], tn0 = v0 ? nprop[p0] : 0, tn1 = v1 ? nprop[p1] : 0;
+    // f[0], f[1]: labels lane, 64 + lane of p0;  f[2], f[3]: of p1;  f[4]: labels 128 + (lane & 31) of p0 (lanes 0..31) / p1 (32..63)
+    const int half = lane >> 5;
+    uint32_t fq[3], f[5];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int k = lane + 64 * j;
-        fp[j] = k < pn ? flow_bias(proposals[(size_t)ppix * LP + k]) : 0u;   // 0: far from every biased flow
-        fcv[j] = k < tn ? flow_bias(proposals[(size_t)pix * LP + k]) : 0u;
-        s_cols[wv][k] = fp[j];
+        fq[j] = k < pn ? flow_bias(proposals[(size_t)q * LP + k]) : 0u;      // 0: far from every biased flow
+        s_cols[wv][k] = fq[j];
     }
-    if (dir == 0) {                                          // the pixel's label data, once (both directions read it)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int k = lane + 64 * j;
+        f[j] = k < tn0 ? flow_bias(proposals[(size_t)p0 * LP + k]) : 0u;
+        f[2 + j] = k < tn1 ? flow_bias(proposals[(size_t)p1 * LP + k]) : 0u;
+    }
+    {
+        const int k = 128 + (lane & 31);
+        f[4] = k < (half ? tn1 : tn0) ? flow_bias(proposals[(size_t)(half ? p1 : p0) * LP + k]) : 0u;
+    }
+    // q's label data, once (both directions read it)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int k = lane + 64 * j;
+        if (k < LP) pl.lab[(size_t)q * LP + k] = make_uint2(fq[j], __float_as_uint(k < pn ? lcosts[(size_t)q * LP + k] : DFLOW_FILL_COST));
+    }
+    // a chain start has no transition into it: empty first blocks (the chain kernel reads all LP of them)
+    if (start0 || start1) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int k = lane + 64 * j;
-            if (k < LP) pl.lab[(size_t)pix * LP + k] = make_uint2(fcv[j], __float_as_uint(k < tn ? lcosts[(size_t)pix * LP + k] : DFLOW_FILL_COST));
+            if (k < LP) {
+                if (start0) pl.blkA[((size_t)q * 2 + 0) * LP + k] = make_uint2(BLK_EMPTY_X, BLK_EMPTY_Y);
+                if (start1) pl.blkA[((size_t)q * 2 + 1) * LP + k] = make_uint2(BLK_EMPTY_X, BLK_EMPTY_Y);
+            }
         }
     }
-    // lanes = labels of this pixel (three groups of 64), predecessor labels come one by one as wave-uniform scalars
-    // (scalar loads of the predecessor's row): D = sad + (2^31 - tpsi) has bit 31 set iff the pair is NOT compatible,
-    // v_alignbit shifts that bit into the row word.  Columns run downwards inside each 32-bit word so that column c ends
-    // up in bit c; columns >= pn (fill values) are forced to "not compatible" afterwards.
+    if (!v0 && !v1) return;
+    // lanes = labels of the successors (five groups of 64), q's labels come one by one as wave-uniform scalars (scalar
+    // loads of q's row): D = sad + (2^31 - tpsi) has bit 31 set iff the pair is NOT compatible, v_alignbit shifts that bit
+    // into the row word.  Columns run downwards inside each 32-bit word so that column c ends up in bit c; columns >= pn
+    // (fill values) are forced to "not compatible" afterwards.
     const uint32_t kbias = 0x80000000u - (uint32_t)tpsi;
-    const uint32_t *__restrict__ colp = proposals + (size_t)ppix * LP;
-    uint32_t m[3][BCD_MASK_WORDS];
-    // a pixel with at most 128 labels (44 % of the frame: fewer than 25 window cells) has no third lane group: its rows stay
-    // "not compatible" and are never used
-    auto build = [&](auto third) {
+    const uint32_t *__restrict__ colp = proposals + (size_t)q * LP;
+    uint32_t m[5][BCD_MASK_WORDS];
+    // pixels with at most 128 labels (44 % of the frame: fewer than 25 window cells) have no labels in the fifth group
+    const bool fifth = LP > 128 && (tn0 > 128 || tn1 > 128);
+    auto build = [&](auto with5) {
 #pragma unroll
         for (int j = 0; j < BCD_MASK_WORDS; j++) {
-            m[0][j] = m[1][j] = m[2][j] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int g = 0; g < 5; g++) m[g][j] = 0xFFFFFFFFu;
             if (32 * j < pn) {
 #pragma unroll
                 for (int cc = 31; cc >= 0; cc--) {
                     const uint32_t col = flow_bias(colp[32 * j + cc]);
-                    m[0][j] = __builtin_amdgcn_alignbit(m[0][j], __builtin_amdgcn_sad_u16(col, fcv[0], kbias), 31);
-                    m[1][j] = __builtin_amdgcn_alignbit(m[1][j], __builtin_amdgcn_sad_u16(col, fcv[1], kbias), 31);
-                    if (decltype(third)::value) m[2][j] = __builtin_amdgcn_alignbit(m[2][j], __builtin_amdgcn_sad_u16(col, fcv[2], kbias), 31);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) m[g][j] = __builtin_amdgcn_alignbit(m[g][j], __builtin_amdgcn_sad_u16(col, f[g], kbias), 31);
+                    if (decltype(with5)::value) m[4][j] = __builtin_amdgcn_alignbit(m[4][j], __builtin_amdgcn_sad_u16(col, f[4], kbias), 31);
                 }
                 const int nv = pn - 32 * j;                  // valid columns in this word (wave-uniform)
                 const uint32_t inval = nv >= 32 ? 0u : ~0u << nv;
-                m[0][j] |= inval; m[1][j] |= inval; m[2][j] |= inval;
+#pragma unroll
+                for (int g = 0; g < 5; g++) m[g][j] |= inval;
             }
         }
     };
-    if (tn > 128) build(BcdC<1>()); else build(BcdC<0>());
-    const size_t rowbase = ((size_t)pix * 2 + dir) * (size_t)LP;
-    const size_t pdbase = (size_t)pix * 2 + dir;
-#pragma unroll
-    for (int grp = 0; grp < 3; grp++) {
-        const int tl = 64 * grp + lane;
-        if (64 * grp >= LP) break;                           // wave-uniform
-        // the first 15 members as bytes and their pairwise costs as nibbles.  Both lists are shift registers filled
-        // from the top (position-independent inserts) and moved down to their final place afterwards.  Labels beyond the
-        // pixel's count (and every label of a chain start) get an empty first block: the chain kernel reads all LP of them.
+    if (fifth) build(BcdC<1>()); else build(BcdC<0>());
+
+    // One group of 64 labels: member lists, blocks, pool rows.  MERGED = the fifth group (two pixels, 32 labels each): label,
+    // count and output rows are per lane, ranks are taken inside each half.
+    auto emit = [&](auto mergedc, const uint32_t (&mg)[BCD_MASK_WORDS], const uint32_t me, const int ig, const int tl, const int tn,
+                    const bool valid, const size_t pd) {
+        constexpr bool MERGED = decltype(mergedc)::value != 0;
+        // the first 15 members as bytes and their pairwise costs as nibbles.  Labels beyond the pixel's count get an empty
+        // first block: the chain kernel reads all LP of them.
         uint32_t w[BCD_MASK_WORDS];
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < BCD_MASK_WORDS; j++) { w[j] = tl < tn ? ~m[grp][j] : 0u; cnt += __popc(w[j]); }
+        for (int j = 0; j < BCD_MASK_WORDS; j++) { w[j] = valid && tl < tn ? ~mg[j] : 0u; cnt += __popc(w[j]); }
         // the first 15 members as bytes: every lane appends to its 16-byte row in LDS (one ds_write_b8 and a pointer
         // increment per member; a shift register in VGPRs costs four instructions per member of the wave's LONGEST list) and
         // reads the row back in place
         uint8_t *row = &s_list[wv][lane][0];
         *reinterpret_cast<uint4 *>(row) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        const uint32_t me = fcv[grp];
         int n = 0;
-        if (64 * grp < tn) {                                 // wave-uniform
+        const bool any = __ballot(cnt > 0) != 0ull;           // wave-uniform
+        if (any) {
 #pragma unroll
             for (int j = 0; j < BCD_MASK_WORDS; j++) {
                 uint32_t ww = w[j];
@@ -178,15 +205,15 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
         const uint32_t l0 = lst.x, l1 = lst.y, l2 = lst.z, l3 = lst.w;
         // the members' pair costs, all at once (4 instructions per slot; in the loop they cost 5 per iteration of the
         // longest list): |dy-dy'| + |dx-dx'| against the member's flow; empty slots (0xFF) read a valid word and are zeroed
-        uint32_t p0 = 0u, p1 = 0u;
-        if (64 * grp < tn) {
+        uint32_t c0 = 0u, c1 = 0u;
+        if (any) {
             auto slots = [&](auto lo, auto hi) {
 #pragma unroll
                 for (int e = decltype(lo)::value; e < decltype(hi)::value; e++) {
                     const uint32_t word = e < 4 ? l0 : (e < 8 ? l1 : (e < 12 ? l2 : l3));
                     const uint32_t k = (word >> (8 * (e & 3))) & 0xFFu;
                     const uint32_t psi = e < n ? flow_l1_biased(me, s_cols[wv][min(k, 191u)]) : 0u;    // k < 160, or 0xFF (empty slot) -> 191: inside the row
-                    if (e < 8) p0 |= psi << (4 * e); else p1 |= psi << (4 * (e - 8));
+                    if (e < 8) c0 |= psi << (4 * e); else c1 |= psi << (4 * (e - 8));
                 }
             };
             // slots 5..9 / 10..14 only if some label of the wave has that many members (wave-uniform: 97 % / 25 % of the waves)
@@ -197,13 +224,14 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
             }
         }
         // bytes 0..3 | 4, 5..8 | 9, 10..13 | 14 and nibbles 0..4, 5..9, 10..14 -> the three blocks
-        const unsigned long long pp = ((unsigned long long)p1 << 32) | p0;
-        // second / third blocks: compacted per wave in lane order (rank = number of lower lanes that own one); the first
-        // BCD_CAP_B / BCD_CAP_C owners get a slot
+        const unsigned long long pp = ((unsigned long long)c1 << 32) | c0;
+        // second / third blocks: compacted per 64-label wave of a pixel in lane order (rank = number of lower lanes of the
+        // same pixel that own one); the first BCD_CAP_B / BCD_CAP_C owners get a slot
         const unsigned long long hasB = __ballot(cnt > BCD_BLK), hasC = __ballot(cnt > 2 * BCD_BLK);
-        const uint32_t rankB = __builtin_amdgcn_mbcnt_hi((uint32_t)(hasB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasB, 0u));
-        const uint32_t rankC = __builtin_amdgcn_mbcnt_hi((uint32_t)(hasC >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasC, 0u));
-        const uint32_t capB = grp < 2 ? BCD_CAP_B01 : BCD_CAP_B2, capC = grp < 2 ? BCD_CAP_C01 : BCD_CAP_C2;
+        uint32_t rankB = __builtin_amdgcn_mbcnt_hi((uint32_t)(hasB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasB, 0u));
+        uint32_t rankC = __builtin_amdgcn_mbcnt_hi((uint32_t)(hasC >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hasC, 0u));
+        if (MERGED && half) { rankB -= (uint32_t)__popc((uint32_t)hasB); rankC -= (uint32_t)__popc((uint32_t)hasC); }
+        const uint32_t capB = ig < 2 ? BCD_CAP_B01 : BCD_CAP_B2, capC = ig < 2 ? BCD_CAP_C01 : BCD_CAP_C2;
         const bool storeB = cnt > BCD_BLK && rankB < capB, storeC = cnt > 2 * BCD_BLK && storeB && rankC < capC;
         const bool more = cnt > BCD_LIST || (cnt > BCD_BLK && !storeB) || (cnt > 2 * BCD_BLK && !storeC);
         const uint32_t ax = l0;
@@ -214,24 +242,42 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
         const uint32_t by = ((l2 >> 8) & 0xFFu) | (((uint32_t)(pp >> 20) & 0xFFFFFu) << 8);
         const uint32_t cx = __builtin_amdgcn_alignbit(l3, l2, 16);
         const uint32_t cy = ((l3 >> 16) & 0xFFu) | (((uint32_t)(pp >> 40) & 0xFFFFFu) << 8);
-        if (tl < LP) pl.blkA[rowbase + tl] = make_uint2(ax, ay);
-        if (storeB) pl.blkBC[pdbase * BCD_ROW_BC + grp * BCD_CAP_B01 + rankB] = make_uint2(bx, by);
-        if (storeC) pl.blkBC[pdbase * BCD_ROW_BC + BCD_ROW_B + grp * BCD_CAP_C01 + rankC] = make_uint2(cx, cy);
-        // the 160-bit rows of the labels marked "more": one allocation per wave from the pool, in lane order
+        if (valid && tl < LP) pl.blkA[pd * (size_t)LP + tl] = make_uint2(ax, ay);
+        if (storeB) pl.blkBC[pd * BCD_ROW_BC + ig * BCD_CAP_B01 + rankB] = make_uint2(bx, by);
+        if (storeC) pl.blkBC[pd * BCD_ROW_BC + BCD_ROW_B + ig * BCD_CAP_C01 + rankC] = make_uint2(cx, cy);
+        // the 160-bit rows of the labels marked "more": one allocation per wave from the pool, in lane order (of each pixel)
         const unsigned long long dense = __ballot(more);
         if (dense) {                                         // wave-uniform
             uint32_t base = 0u;
             if (lane == 0) base = atomicAdd(pl.cursor, (uint32_t)__popcll(dense));
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (lane == 0) reinterpret_cast<uint32_t *>(pl.blkBC + pdbase * BCD_ROW_BC + BCD_ROW_B + BCD_ROW_C)[grp] = base;
-            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dense >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dense, 0u));
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dense >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dense, 0u));
+            if (MERGED) {
+                // the upper half's rows follow the lower half's; every pixel's base goes to its own row
+                const uint32_t nlo = (uint32_t)__popc((uint32_t)dense);
+                if ((lane & 31) == 0 && (half ? (dense >> 32) != 0ull : (uint32_t)dense != 0u))
+                    reinterpret_cast<uint32_t *>(pl.blkBC + pd * BCD_ROW_BC + BCD_ROW_B + BCD_ROW_C)[ig] = base + (half ? nlo : 0u);
+            } else if (lane == 0) {
+                reinterpret_cast<uint32_t *>(pl.blkBC + pd * BCD_ROW_BC + BCD_ROW_B + BCD_ROW_C)[ig] = base;
+            }
+            const uint32_t slot = base + rank;                // the rank inside a pixel's labels = rank - (rows of the lower half)
             if (more && slot < pl.pool_rows) {
                 uint32_t *out = pl.masks + (size_t)slot * BCD_MASK_WORDS;
 #pragma unroll
                 for (int j = 0; j < BCD_MASK_WORDS; j++) out[j] = w[j];
             }
         }
+    };
+    const size_t pd0 = (size_t)p0 * 2 + 0, pd1 = (size_t)p1 * 2 + 1;
+    if (v0) {
+        emit(BcdC<0>(), m[0], f[0], 0, lane, tn0, true, pd0);
+        if (LP > 64) emit(BcdC<0>(), m[1], f[1], 1, 64 + lane, tn0, true, pd0);
     }
+    if (v1) {
+        emit(BcdC<0>(), m[2], f[2], 0, lane, tn1, true, pd1);
+        if (LP > 64) emit(BcdC<0>(), m[3], f[3], 1, 64 + lane, tn1, true, pd1);
+    }
+    if (LP > 128) emit(BcdC<1>(), m[4], f[4], 2, 128 + (lane & 31), half ? tn1 : tn0, half ? v1 : v0, half ? pd1 : pd0);
 }
 
 // ------------------------------------------------------------------------------------------------ chains
@@ -729,7 +775,7 @@ static BcdPlanes planes_of(const dflow_params *p, void *ws)
 int launch_bcd_prepare(const dflow_params *p, const uint32_t *proposals, const float *lcosts, const int32_t *nprop, void *ws,
                        hipStream_t s)
 {
-    long long items = 2LL * p->pich * p->picw;
+    long long items = (long long)p->pich * p->picw;          // one wave per pixel (as the predecessor of two others)
     if (hipMemsetAsync(planes_of(p, ws).cursor, 0, 256, s) != hipSuccess)
         return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_bcd_prepare");
     hipLaunchKernelGGL(bcd_lists_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p->pich, p->picw, p->label_pitch,
