@@ -189,16 +189,25 @@ __global__ void __launch_bounds__(256) bcd_lists_kernel(int H, int W, int LP, in
         // reads the row back in place
         uint8_t *row = &s_list[wv][lane][0];
         *reinterpret_cast<uint4 *>(row) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        int n = 0;
+        const int n = min(cnt, BCD_LIST);
         const bool any = __ballot(cnt > 0) != 0ull;           // wave-uniform
         if (any) {
+            // rows with more than BCD_LIST members (0.2 % of the labels) are cut back to their first BCD_LIST members, so
+            // that the loops below need no capacity test (9 -> 7 instructions per member of the wave's longest list)
+            uint32_t wt[BCD_MASK_WORDS];
+#pragma unroll
+            for (int j = 0; j < BCD_MASK_WORDS; j++) wt[j] = w[j];
+            if (__ballot(cnt > BCD_LIST)) {
+                int extra = cnt - BCD_LIST;
+#pragma unroll
+                for (int j = BCD_MASK_WORDS - 1; j >= 0; j--)
+                    while (extra > 0 && wt[j]) { wt[j] &= ~(0x80000000u >> __clz(wt[j])); extra--; }
+            }
+            uint8_t *ap = row;
 #pragma unroll
             for (int j = 0; j < BCD_MASK_WORDS; j++) {
-                uint32_t ww = w[j];
-                while (ww && n < BCD_LIST) {
-                    row[n] = (uint8_t)(32 * j + __ffs(ww) - 1); ww &= ww - 1;
-                    n++;
-                }
+                uint32_t ww = wt[j];
+                while (ww) { *ap++ = (uint8_t)(32 * j + __ffs(ww) - 1); ww &= ww - 1; }
             }
         }
         const uint4 lst = *reinterpret_cast<const uint4 *>(row);
