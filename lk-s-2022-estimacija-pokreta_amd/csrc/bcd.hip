@@ -6,8 +6,9 @@
 //                      chains (column chain / row chain) and every label tl of p, the set { k : tpsi > |dy-dy'|+|dx-dx'|
 //                      between label tl of p and label k of p's predecessor on that chain } -- the reference's
 //                      packedksets (Q8), restricted to the two neighbours that are ever used and already transposed
-//                      for the direction in which the chain runs.  lanes = labels of p, the predecessor's labels are
-//                      wave-uniform: one v_sad_u16 + one v_alignbit per pair builds the 160-bit row in registers.  What
+//                      for the direction in which the chain runs.  One wave per PREDECESSOR pixel: its labels are
+//                      wave-uniform, lanes = the labels of its two successors (column chain, row chain); one v_sad_u16 +
+//                      one v_alignbit per 64 pairs builds the 160-bit rows in registers.  What
 //                      the chain kernel streams is compact: per (pixel, direction, label) ONE 8-byte block with the first 5
 //                      members (index bytes + their pair costs) and the member count; labels with more than 5 (21 %) /
 //                      more than 10 (2.6 %) members own a second / third block, stored COMPACTED per 64-label wave (ballot
