@@ -316,8 +316,9 @@ class GpuEngine:
 
 class BatchEngine:
     """Steps are processed in groups of `batch` pairs: the front end of every pair of a group (DAISY, kNN proposals,
-    neighbour proposals, compat lists) runs on one of `front` HIP streams, then the BCD sweeps of the whole group run as
-    ONE batched launch per phase (dflow_bcd_sweep_batch: chains x passes in one grid), then labels -> flow and the gather.
+    neighbour proposals) runs on one of `front` HIP streams, then, on the BCD stream, the compat lists of the group's pairs
+    (the front end paces the pipeline, the BCD stream has slack: 10.96 vs 11.07 ms per step) and the BCD sweeps of the whole
+    group as ONE batched launch per phase (dflow_bcd_sweep_batch: chains x passes in one grid), then labels -> flow and the gather.
     Two sets of per-pair state alternate, so the front end of group g+1 overlaps the sweeps of group g.  Every step is
     still one complete pass over one pair; the timed region contains exactly `steps` of them (the last group may be
     smaller)."""
@@ -342,6 +343,7 @@ class BatchEngine:
         self.flows = self.sets[0]
         self.front = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, args.front))]
         self.bcd_stream = torch.cuda.Stream(device=self.dev)
+        self.lists_on_bcd = not bool(getattr(args, "lists_on_front", False))
         self.set_free = [None, None]            # event: the set's previous sweeps + flow read-out are done
         self.seeds = [self.synth.pair_seed(2 * rank + j, 0) for j in range(2)]
         self.pairs = []
@@ -391,13 +393,17 @@ class BatchEngine:
                 df.load_pair(a, b)
                 df.generisi()
                 df.nasumicni()
-                df.pakovanje()
+                if not self.lists_on_bcd:
+                    df.pakovanje()
                 e = torch.cuda.Event()
                 e.record()
                 evs.append(e)
         with torch.cuda.stream(self.bcd_stream):
             for e in evs:
                 self.bcd_stream.wait_event(e)
+            if self.lists_on_bcd:
+                for df in dfs:
+                    df.pakovanje()
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -615,8 +621,8 @@ def finish_report(out, eng, args, world):
     out["config"] = {"workload": "single 1024x436 Sintel-shape pair per step per GPU, forward only, bcd_times=4 "
                                  "(BASELINE.json configs[1]); cells 64x27, 150 labels/px",
                      "pairs_in_flight_per_gpu": P, "pair_seeds_rank0": eng.seeds, "mode": args.mode,
-                     "parallelism": ("one pass per step, steps in equal groups of at most %d: front end of a group's pairs on %d HIP streams, the "
-                                     "BCD sweeps of the group as one batched launch per phase (chains x passes), two groups "
+                     "parallelism": ("one pass per step, steps in equal groups of at most %d: front end of a group's pairs (DAISY, kNN, neighbour proposals) on %d HIP streams, "
+                                     "their compat lists and the BCD sweeps of the group on a fourth: one batched launch per phase (chains x passes), two groups "
                                      "alternate so that front end and sweeps of consecutive groups overlap; flow fields gathered "
                                      "on rank 0" % (P, args.front)) if args.mode == "batch" else
                                     ("one pass per step; %d independent steps in flight per GPU on separate HIP streams; "
@@ -700,6 +706,7 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks on device 0, gather over gloo (a multi-rank rehearsal on a one-GPU box; not a measurement)")
     ap.add_argument("--groups", default=None, help=argparse.SUPPRESS)    # experiment: explicit group sizes of the timed region
+    ap.add_argument("--lists-on-front", action="store_true", help=argparse.SUPPRESS)    # experiment: compat lists on the front-end streams (before round 3: the default)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
