@@ -316,9 +316,9 @@ class GpuEngine:
 
 class BatchEngine:
     """Steps are processed in groups of `batch` pairs: the front end of every pair of a group (DAISY, kNN proposals,
-    neighbour proposals) runs on one of `front` HIP streams, then, on the BCD stream, the compat lists of the group's pairs
-    (the front end paces the pipeline, the BCD stream has slack: 10.96 vs 11.07 ms per step) and the BCD sweeps of the whole
-    group as ONE batched launch per phase (dflow_bcd_sweep_batch: chains x passes in one grid), then labels -> flow and the gather.
+    neighbour proposals) runs on one of `front` HIP streams, the compat lists of a pair follow on a stream of their own as
+    soon as that pair is ready (the front end paces the pipeline: 10.96 vs 11.07 ms per step with the lists off its streams),
+    then the BCD sweeps of the whole group run on the BCD stream as ONE batched launch per phase (dflow_bcd_sweep_batch: chains x passes in one grid), then labels -> flow and the gather.
     Two sets of per-pair state alternate, so the front end of group g+1 overlaps the sweeps of group g.  Every step is
     still one complete pass over one pair; the timed region contains exactly `steps` of them (the last group may be
     smaller)."""
@@ -344,6 +344,8 @@ class BatchEngine:
         self.front = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, args.front))]
         self.bcd_stream = torch.cuda.Stream(device=self.dev)
         self.lists_on_bcd = not bool(getattr(args, "lists_on_front", False))
+        # the lists of a pair start as soon as that pair's front end is done (a stream of their own), not when the whole group is
+        self.lists_stream = torch.cuda.Stream(device=self.dev) if self.lists_on_bcd and not getattr(args, "no_lists_stream", False) else None
         self.set_free = [None, None]            # event: the set's previous sweeps + flow read-out are done
         self.seeds = [self.synth.pair_seed(2 * rank + j, 0) for j in range(2)]
         self.pairs = []
@@ -398,10 +400,20 @@ class BatchEngine:
                 e = torch.cuda.Event()
                 e.record()
                 evs.append(e)
+        if self.lists_stream is not None:
+            evs2 = []
+            with torch.cuda.stream(self.lists_stream):
+                for e, df in zip(evs, dfs):
+                    self.lists_stream.wait_event(e)
+                    df.pakovanje()
+                    e2 = torch.cuda.Event()
+                    e2.record()
+                    evs2.append(e2)
+            evs = evs2
         with torch.cuda.stream(self.bcd_stream):
             for e in evs:
                 self.bcd_stream.wait_event(e)
-            if self.lists_on_bcd:
+            if self.lists_on_bcd and self.lists_stream is None:
                 for df in dfs:
                     df.pakovanje()
             if timed:
@@ -622,7 +634,7 @@ def finish_report(out, eng, args, world):
                                  "(BASELINE.json configs[1]); cells 64x27, 150 labels/px",
                      "pairs_in_flight_per_gpu": P, "pair_seeds_rank0": eng.seeds, "mode": args.mode,
                      "parallelism": ("one pass per step, steps in equal groups of at most %d: front end of a group's pairs (DAISY, kNN, neighbour proposals) on %d HIP streams, "
-                                     "their compat lists and the BCD sweeps of the group on a fourth: one batched launch per phase (chains x passes), two groups "
+                                     "their compat lists on a fourth, the BCD sweeps of the group on a fifth: one batched launch per phase (chains x passes), two groups "
                                      "alternate so that front end and sweeps of consecutive groups overlap; flow fields gathered "
                                      "on rank 0" % (P, args.front)) if args.mode == "batch" else
                                     ("one pass per step; %d independent steps in flight per GPU on separate HIP streams; "
@@ -706,6 +718,7 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks on device 0, gather over gloo (a multi-rank rehearsal on a one-GPU box; not a measurement)")
     ap.add_argument("--groups", default=None, help=argparse.SUPPRESS)    # experiment: explicit group sizes of the timed region
+    ap.add_argument("--no-lists-stream", action="store_true", help=argparse.SUPPRESS)   # experiment: compat lists on the BCD stream itself
     ap.add_argument("--lists-on-front", action="store_true", help=argparse.SUPPRESS)    # experiment: compat lists on the front-end streams (before round 3: the default)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
