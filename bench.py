@@ -704,7 +704,7 @@ def finish_report(out, eng, args, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)       # 12 groups of 8: the fill and drain of the two-group pipeline weigh < 10 %
+    ap.add_argument("--steps", type=int, default=98)       # 14 groups of 7: the fill and drain of the two-group pipeline weigh < 10 %
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the one-GPU timings of BASELINE configs[2] and [4]")
@@ -712,7 +712,7 @@ def main():
                     help="independent pairs in flight per GPU (each on its own HIP stream and workspace)")
     ap.add_argument("--mode", choices=("streams", "batch"), default="batch",
                     help="streams: --inflight independent pipelines; batch: groups of --batch pairs share the BCD launches")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=7,
                     help="largest group in --mode batch (the steps are split into equal groups of at most this many pairs)")
     ap.add_argument("--front", type=int, default=3, help="HIP streams for the front end of a group in --mode batch")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
