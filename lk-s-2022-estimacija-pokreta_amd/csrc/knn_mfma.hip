@@ -140,11 +140,13 @@ __global__ void __launch_bounds__(1024) knn_mean_kernel(const T *__restrict__ d,
 __device__ static inline _Float16 km_f16_up(double v) { return (_Float16)(float)(v * 1.001 + 1e-7); }
 
 // which = 0: image 1 (queries), one thread per pixel, rows in pixel order.  which = 1: image 2 (candidates), one thread
-// per (cell = blockIdx.y, tile position), rows in position order (above).  The rotation y_j = sum_i V[j][i] x_i is a float32
-// fmaf chain; the components of V arrive through the scalar cache (vt is wave-uniform), 8 components per iteration = one
-// 16-byte store.  Its rounding is part of E: |y^_j - y_j| <= gamma_68 sum_i |V_ji x_i| <= 68 * 2^-24 (1 + 5e-6) |x|, over
-// the 42 components |y^ - y_P| <= 2.63e-5 |x| (KM_RHO also holds the 6.2e-8 |x| of the rounding of d - mu).
+// per (cell = blockIdx.y, tile position), rows in position order (above).  The rotation y_j = sum_i V[j][i] x_i runs as two
+// float32 fmaf chains (even / odd dimensions: one chain of packed fmas) that are added at the end; the components of V arrive
+// through the scalar cache (vt is wave-uniform), 8 components per iteration = one 16-byte store.  Its rounding is part of E:
+// for ANY order of the 68 additions |y^_j - y_j| <= gamma_68 sum_i |V_ji x_i| <= 68 * 2^-24 (1 + 5e-6) |x|, over the 42
+// components |y^ - y_P| <= 2.63e-5 |x| (KM_RHO also holds the 6.2e-8 |x| of the rounding of d - mu).
 #define KM_RHO 2.65e-5
+typedef float km_f2p __attribute__((ext_vector_type(2)));
 template <typename T>
 __global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, const float *__restrict__ mu,
                                                        const float *__restrict__ vt, _Float16 *__restrict__ h,
@@ -190,10 +192,12 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, 
     }
     double ss = 0.0, sx = 0.0, se = 0.0;        // |y~|^2, |y^|^2, |y~ - y^|^2 over the KM_KD leading components
     auto component = [&](int j) -> _Float16 {
-        const float *__restrict__ vj = vt + (size_t)j * DFLOW_DESC;
-        float y = 0.0f;
+        // two fmaf chains (even / odd dimensions) as ONE chain of v_pk_fma_f32: half the instructions of a single chain
+        const km_f2p *__restrict__ vj = reinterpret_cast<const km_f2p *>(vt + (size_t)j * DFLOW_DESC);
+        km_f2p acc = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < DFLOW_DESC; i++) y = __fmaf_rn(vj[i], x[i], y);
+        for (int i = 0; i < DFLOW_DESC / 2; i++) acc = __builtin_elementwise_fma(vj[i], (km_f2p){x[2 * i], x[2 * i + 1]}, acc);
+        const float y = acc.x + acc.y;
         bad |= (__float_as_uint(y) & 0x7FFFFFFFu) >= 0x476A6000u;
         const _Float16 hv = (_Float16)y;
         const double f = (double)(float)hv, yd = (double)y, er = f - yd;
