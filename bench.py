@@ -624,6 +624,19 @@ def other_configs(eng, args):
                                   "ms": best, "ms_mean": mean, "passes": 4, "ms_per_pass": best / 4, "Mpix/s": 4 * kh * kw / best / 1e3,
                                   "dtype": "f16 descriptors / f32 distance / f64 DP"}
     del kdfs
+    # 1920x1080: not a BASELINE configuration; the largest frame the workspace layout is sized for, 2 passes
+    fh, fw, fch, fcw = 1080, 1920, 40, 30
+    fdfs = [pl.DiscreteFlow(fh, fw, fch, fcw, device=dev, seed=0) for _ in range(2)]
+    jobs = []
+    for pr in range(2):
+        i1, i2, _ = synth.make_pair(fh, fw, seed=synth.pair_seed(pr, 0))
+        jobs.append((torch.from_numpy(i1).to(dev), torch.from_numpy(i2).to(dev)))
+    best, mean = timed(lambda: run_passes(fdfs, jobs, BCD_TIMES, streams), reps=2)
+    res["1920x1080"] = {"workload": "1920x1080 (not in BASELINE.json), cells 30x40 px = the bench's 64x27 grid, forward passes of 2 synthetic pairs, "
+                                    "bcd_times=%d, 1 GPU; workspace %.1f GB per pass" % (BCD_TIMES, fdfs[0].ws_bytes / 1e9),
+                        "ms": best, "ms_mean": mean, "passes": 2, "ms_per_pass": best / 2, "Mpix/s": 2 * fh * fw / best / 1e3,
+                        "dtype": "f32 descriptors / f32 distance / f64 DP"}
+    del fdfs
     return res
 
 

@@ -660,6 +660,7 @@ def test_bench_contract(torch_, tmp_path):
     oc = d["other_configs"]
     assert oc["configs[2]"]["passes"] == 2 and oc["configs[2]"]["ms"] > 0
     assert oc["configs[4] geometry"]["dtype"].startswith("f16 descriptors") and oc["configs[4] geometry"]["ms_per_pass"] > 0
+    assert oc["1920x1080"]["passes"] == 2 and oc["1920x1080"]["ms_per_pass"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "Mpix/s" and 0 < c["value"] < d["value"]
     assert len(c["entries"]) == 3 and c["entries"][2]["threads"] == 1 and "1241x375" in c["entries"][1]["config"]
