@@ -368,7 +368,9 @@ class BatchEngine:
         else:
             ngroups = max(1, -(-nsteps // self.B))          # groups of equal size, at most `batch` pairs each
             q, r = divmod(nsteps, ngroups)
-            self.plan = [q + 1] * r + [q] * (ngroups - r)
+            # the smaller groups first: the first group's front end has no sweeps to overlap with (20 steps as 6, 7, 7: 11.06 ms
+            # per step; as 7, 7, 6: 11.23)
+            self.plan = [q] * (ngroups - r) + [q + 1] * r
         self.plan_at = 0
 
     def step(self, i, timed):
