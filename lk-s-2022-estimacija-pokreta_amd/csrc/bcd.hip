@@ -546,17 +546,19 @@ __global__ void __launch_bounds__(BCD_THREADS, BCD_MINWAVES) bcd_chain_kernel(Bc
         const float lc = __uint_as_float(inL.y);
         const unsigned long long actmask = ballot64(tl < tn) & ownmask;
         const bool act = owner && tl < tn;
-        inA = ld8(pA, offl); inL = ld8(pL, offl); advA();
-        fetchBC(nxA, inB, inC);
         // min over compatible previous labels (python bcd.py:163-176 / :198-219) in increasing k (strict '<' keeps the
         // first minimum).  Members come as index bytes in increasing k (0xFF = none, which reads the +inf tail of dp)
-        // with their pair costs; candidates are tracked by their dp offset 8 k.
+        // with their pair costs; candidates are tracked by their dp offset 8 k.  Their dp values are requested FIRST (the
+        // block has been in registers for four steps): the prefetches and the block bookkeeping below run while LDS answers.
         uint32_t ad[BCD_BLK]; double dd[BCD_BLK];
 #pragma unroll
         for (int j = 0; j < BCD_BLK; j++) {
             ad[j] = ((j < 4 ? ax >> (8 * j) : ay) & 0xFFu) << 3;
             dd[j] = *reinterpret_cast<const double *>(prev + ad[j]);
         }
+        asm volatile("" ::: "memory");              // keeps the LDS reads in front of what follows
+        inA = ld8(pA, offl); inL = ld8(pL, offl); advA();
+        fetchBC(nxA, inB, inC);
         // permmincost / permminlabel (python bcd.py:152-157) merged from the per-wave partials of the previous step (waves
         // are in label order and every partial index is the first one inside its wave), and the unary term
         // small = (lamda*lcost + s1) + s2 (python bcd.py:161-162; a side neighbour outside the chain contributes 0: its
