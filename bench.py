@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 PKG = "lk-s-2022-estimacija-pokreta_amd"
 
 H, W, BCD_TIMES = 436, 1024, 4
+LONG_STEPS = 98                # the default --steps; a run with another --steps adds one timed region of this length
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (the kNN screen runs on f16 MFMA)
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc passes of this command (tracked)
@@ -96,6 +97,17 @@ def knn_pairs(pich, picw, cellh, cellw, window=2):
     return sx * sy
 
 
+def mean_window_cells(pich, picw, cellh, cellw, window=2):
+    """Mean number of cells in a pixel's search window (25 in the interior, fewer at the border and on small frames): the
+    CPU cost per pixel is proportional to it, so Mpix/s of frames with different values do not compare directly."""
+    ncx, ncy = picw // cellw, pich // cellh
+    wx = [(picw if c == ncx - 1 else (c + 1) * cellw) - c * cellw for c in range(ncx)]
+    wy = [(pich if c == ncy - 1 else (c + 1) * cellh) - c * cellh for c in range(ncy)]
+    sx = sum(wx[c] * (min(ncx - 1, c + window) - max(0, c - window) + 1) for c in range(ncx))
+    sy = sum(wy[c] * (min(ncy - 1, c + window) - max(0, c - window) + 1) for c in range(ncy))
+    return sx * sy / float(pich * picw)
+
+
 def epe_stats(flow, gt, mask=None):
     """Mean / median end-point error and % > 3 px (metric of visualization.py:128-152) of a (H,W,2) [dy,dx] field."""
     import numpy as np
@@ -143,15 +155,18 @@ def cpu_baseline(synth, gpu_flow, bench_seed, cellh, cellw):
     dt = time.perf_counter() - t0
     oracle_flow = ref["flows"][-1]
     entries.append({"config": "BASELINE configs[1]: the bench pair, 1024x436, cells %dx%d, forward, bcd_times=%d" % (cellw, cellh, BCD_TIMES),
-                    "value": H * W / dt / 1e6, "unit": "Mpix/s", "threads": threads, "seconds": dt})
+                    "value": H * W / dt / 1e6, "unit": "Mpix/s", "threads": threads, "seconds": dt,
+                    "window_cells_per_pixel": round(mean_window_cells(H, W, cellh, cellw), 2)})
     kh, kw = 125, 365
     a, b, _ = synth.make_pair(kh, kw, seed=synth.pair_seed(6, 0), amp_x=30.0, amp_y=10.0)
     t0 = time.perf_counter()
     O.full_pass(O.make_params(kh, kw, 25, 73, seed=0), a, b, 1)
     dk = time.perf_counter() - t0
     entries.append({"config": "BASELINE configs[0] geometry: cells 73x25 (of 1241x375), idx 6 forward, bcd_times=1, on a 365x125 "
-                              "part (5 x 5 cells: every pixel sees the whole window) of a synthetic pair (KITTI is absent)",
-                    "value": kh * kw / dk / 1e6, "unit": "Mpix/s", "threads": threads, "seconds": dk})
+                              "part (5 x 5 cells) of a synthetic pair (KITTI is absent)",
+                    "value": kh * kw / dk / 1e6, "unit": "Mpix/s", "threads": threads, "seconds": dk,
+                    "window_cells_per_pixel": round(mean_window_cells(kh, kw, 25, 73), 2),
+                    "window_cells_per_pixel_full_frame": round(mean_window_cells(375, 1241, 25, 73), 2)})
     O.set_threads(1)
     sh, sw = 54, 128
     a, b, _ = synth.make_pair(sh, sw, seed=4242, amp_x=12.0, amp_y=6.0)
@@ -160,12 +175,16 @@ def cpu_baseline(synth, gpu_flow, bench_seed, cellh, cellw):
     ds = time.perf_counter() - t0
     entries.append({"config": "128x54 synthetic pair (2 x 2 cells of a Sintel frame: 4 window cells per pixel instead of up to 25), "
                               "cells 64x27, bcd_times=%d, single thread like the reference" % BCD_TIMES,
-                    "value": sh * sw / ds / 1e6, "unit": "Mpix/s", "threads": 1, "seconds": ds})
+                    "value": sh * sw / ds / 1e6, "unit": "Mpix/s", "threads": 1, "seconds": ds,
+                    "window_cells_per_pixel": round(mean_window_cells(sh, sw, 27, 64), 2),
+                    "window_cells_per_pixel_full_frame": round(mean_window_cells(H, W, 27, 64), 2)})
     base = {"value": entries[0]["value"], "unit": "Mpix/s", "cores": threads, "kind": "port",
             "host_cores": host_cores, "usable_cores": usable,
             "sample": "the bench's own 1024x436 pair (whole frame, bcd_times=%d) in %.1f s on %d threads; C restatement of "
                       "daisy i flann.py + python bcd.py (oracle/), exact kNN instead of FLANN; the reference's cv2/FLANN "
                       "native code is absent and cannot be timed" % (BCD_TIMES, dt, threads),
+            "entries_note": "Mpix/s of the entries are not comparable with each other: the work per pixel grows with window_cells_per_pixel "
+                            "(entries 2 and 3 run on sub-frames with fewer window cells than their full frames; the bias favours the CPU)",
             "entries": entries}
     # EPE of both paths against the synthetic ground truth, and their difference (labels are bit-identical => 0)
     m = window_mask(gt, cellh, cellw)
@@ -223,6 +242,47 @@ def stage_rooflines(torch, df, pair, cellh, cellw, reps=3):
     }
 
 
+def csrc_digest():
+    """sha256 (16 hex digits) over the kernel sources: the tracked PMC summaries carry the digest they were collected with."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, PKG, "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h")) or n == "Makefile":
+            with open(os.path.join(d, n), "rb") as f:
+                h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def profiles_state():
+    """(stale, detail): whether profiles/pmc_traffic.json and pmc_knn.json were collected with the kernels that are running now."""
+    now, detail, stale = csrc_digest(), {}, False
+    for n in ("pmc_traffic.json", "pmc_knn.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", n)) as f:
+                was = json.load(f).get("csrc_sha16")
+        except Exception:
+            was = None
+        detail[n] = was
+        stale |= was != now
+    detail["csrc_sha16_now"] = now
+    return stale, detail
+
+
+def total_traffic_per_pass():
+    """HBM bytes of ONE pass summed over every kernel of the profiled bench command (profiles/pmc_traffic.json: bytes per
+    launch x launches / passes profiled), next to the algorithmic bytes: what the whole pipeline moves, not just one kernel."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            d = json.load(f)
+        n = float(d["passes_profiled"])
+        per = {k.split("(")[0]: v["hbm_bytes_per_launch"] * v["launches_in_pass"] / n for k, v in d["kernels"].items()}
+        top = dict(sorted(per.items(), key=lambda kv: -kv[1])[:8])
+        return int(sum(per.values())), {k: int(v) for k, v in top.items()}
+    except Exception:
+        return None, None
+
+
 def pmc_traffic(kernel, unit_grids=None, passes=1.0):
     """HBM bytes per launch of `kernel` from the tracked rocprofv3 --pmc summary (profiles/pmc_traffic.json, written by
     scratch/pmc_to_json.py from separate FETCH_SIZE and WRITE_SIZE passes of the bench command; FETCH_SIZE already doubled as
@@ -256,10 +316,30 @@ def _device_and_backend(args, local_rank):
     return local_rank, "nccl"
 
 
+def _make_jobs(eng, passes):
+    """(image 1, image 2) device tensors of the passes p = 2 * pair + direction (synthetic pair 1000 * pair, the backward
+    pass swaps the images), uploaded once per pair."""
+    imgs, jobs = {}, []
+    for p in passes:
+        q, backward = p // 2, p % 2
+        if q not in imgs:
+            i1, i2, _ = eng.synth.make_pair(H, W, seed=eng.synth.pair_seed(q, 0))
+            imgs[q] = (eng.torch.from_numpy(i1).to(eng.dev), eng.torch.from_numpy(i2).to(eng.dev))
+        a, b = imgs[q]
+        jobs.append((b, a) if backward else (a, b))
+    return jobs
+
+
+def _consistency(eng, fwd, bwd):
+    return eng.pipeline.fb_consistency(fwd, bwd, 10.0, eng.flows[0].p)
+
+
 class GpuEngine:
     """`inflight` independent pipelines per GPU: consecutive steps (= different image pairs) run on different HIP
     streams, so the latency-bound BCD chains of one pair overlap the MFMA-bound kNN screening of the next.  Every step is
     still one complete pass over one pair; the timed region contains exactly `steps` of them."""
+
+    make_jobs, consistency = _make_jobs, _consistency
 
     def __init__(self, args, rank, local_rank, world):
         import torch
@@ -282,6 +362,7 @@ class GpuEngine:
             self.pairs.append((torch.from_numpy(img1).to(self.dev), torch.from_numpy(img2).to(self.dev)))
         self.bcd_events = []
         self.gather = None
+        self.jobs = None
 
     def like(self):
         return self.flows[0].flow
@@ -289,7 +370,7 @@ class GpuEngine:
     def step(self, i, timed):
         torch = self.torch
         df, st = self.flows[i % self.P], self.streams[i % self.P]
-        a, b = self.pairs[i % 2]
+        a, b = self.jobs[i] if self.jobs is not None else self.pairs[i % 2]
         with torch.cuda.stream(st):
             df.load_pair(a, b)
             df.generisi()
@@ -322,6 +403,8 @@ class BatchEngine:
     Two sets of per-pair state alternate, so the front end of group g+1 overlaps the sweeps of group g.  Every step is
     still one complete pass over one pair; the timed region contains exactly `steps` of them (the last group may be
     smaller)."""
+
+    make_jobs, consistency = _make_jobs, _consistency
 
     def __init__(self, args, rank, local_rank, world):
         import torch
@@ -357,6 +440,7 @@ class BatchEngine:
         self.pending = []                       # step indices of the group being collected
         self.group_no = 0
         self.nsteps = None
+        self.jobs = None                        # explicit (image 1, image 2) per step (the fixed batch); None: the two resident pairs in turn
 
     def like(self):
         return self.flows[0].flow
@@ -389,7 +473,7 @@ class BatchEngine:
         evs = []
         for j, i in enumerate(idx):
             st = self.front[j % len(self.front)]
-            a, b = self.pairs[i % 2]
+            a, b = self.jobs[i] if self.jobs is not None else self.pairs[i % 2]
             with torch.cuda.stream(st):
                 if self.set_free[k] is not None:
                     st.wait_event(self.set_free[k])
@@ -450,6 +534,13 @@ class StubEngine:
         self.P = 1
         self.field = torch.full((8, 8, 2), float(rank), dtype=torch.float32)
         self.gather = None
+        self.jobs = None
+
+    def make_jobs(self, passes):
+        return [None] * len(passes)
+
+    def consistency(self, fwd, bwd):
+        return fwd - bwd
 
     def like(self):
         return self.field
@@ -464,6 +555,72 @@ class StubEngine:
 
     def sync(self):
         pass
+
+
+# ---------------------------------------------------------------------------------------------------- fixed batch
+def run_fixed_batch(eng, npasses, world, rank, use_dist, sync_all):
+    """BASELINE configs[3] (README.md:40 of the reference: forward and backward runs are independent): a FIXED batch of
+    npasses = 8 pairs x (forward, backward) passes, pass p -> rank p mod world, every finished field gathered on rank 0
+    (RCCL), the forward/backward consistency check of every pair there (postprocessing.py:123-135).  The total work does
+    not depend on the number of GPUs: strong scaling, next to the headline's weak scaling.  Same engine as the headline
+    (a rank's passes in equal groups, front ends on HIP streams, batched sweeps).  Returns the wall time (max over ranks)."""
+    import torch.distributed as dist
+    sharding = importlib.import_module(PKG + ".sharding")
+    torch = eng.torch
+    mine = sharding.assign_passes(npasses, world, rank)
+    rounds = -(-npasses // world)
+    saved_gather, saved_jobs = eng.gather, eng.jobs
+    eng.jobs = eng.make_jobs(mine)
+    bufs = [sharding.make_gather_buffers(eng.like(), world, rank) for _ in range(eng.P)] if use_dist else None
+    fields, calls = {}, [0]
+
+    def gather(flow, slot):
+        k = calls[0]
+        calls[0] += 1
+        if not use_dist:
+            fields[mine[k]] = flow.clone()
+            return
+        sharding.gather_flows(flow, bufs[slot], rank)
+        if rank == 0:
+            for src in range(world):
+                if k * world + src < npasses:
+                    fields[k * world + src] = bufs[slot][src].clone()
+
+    eng.gather = gather
+
+    def once():
+        calls[0] = 0
+        fields.clear()
+        eng.begin(len(mine))
+        for i in range(len(mine)):
+            eng.step(i, False)
+        eng.sync()
+        for _ in range(len(mine), rounds):                 # ranks with a shorter share keep the gathers collective
+            gather(torch.zeros_like(eng.like()), 0)
+        out = None
+        if rank == 0:
+            out = [eng.consistency(fields[2 * q], fields[2 * q + 1]) for q in range(npasses // 2)]
+        return out
+
+    once()
+    sync_all()
+    t0 = time.perf_counter()
+    sparse = once()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.like().device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.gather, eng.jobs = saved_gather, saved_jobs
+    rec = {"workload": "BASELINE configs[3]: fixed batch of %d passes = %d 1024x436 pairs x (forward, backward), bcd_times=%d, pass p -> rank "
+                       "p mod %d, flow fields gathered on rank 0, forward/backward consistency check (threshold 10) of every pair there"
+                       % (npasses, npasses // 2, BCD_TIMES, world),
+           "passes": npasses, "passes_per_rank": len(mine), "n_gpus": world, "ms": dt * 1e3, "ms_per_pass": dt * 1e3 / npasses,
+           "Mpix/s": npasses * H * W / dt / 1e6, "scaling": "strong"}
+    if rank == 0 and sparse is not None and hasattr(sparse[0], "shape") and sparse[0].dim() == 3 and sparse[0].shape[-1] == 3:
+        rec["consistent_fraction_mean"] = float(sum(float(s_[..., 2].mean()) for s_ in sparse) / len(sparse))
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------------- worker
@@ -512,17 +669,27 @@ def worker(args):
             dist.barrier()
             eng.sync()
 
-    sync_all()
-    t0 = time.perf_counter()
-    eng.begin(args.steps)
-    for i in range(args.steps):
-        eng.step(i, True)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.like().device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_region(nsteps, record):
+        """Exactly nsteps steps between barrier + synchronize on both sides; the maximum over the ranks."""
+        sync_all()
+        t0 = time.perf_counter()
+        eng.begin(nsteps)
+        for i in range(nsteps):
+            eng.step(i, record)
+        sync_all()
+        d = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([d], dtype=torch.float64, device=eng.like().device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d
+
+    dt = timed_region(args.steps, True)
+    # the driver's 20 steps are 0.2 s: one more region of the default length (98 steps, 14 groups of 7: fill and drain of the
+    # two-group pipeline weigh < 10 %) right behind it, reported beside the headline, never instead of it
+    dt_long = timed_region(LONG_STEPS, False) if (args.steps != LONG_STEPS and not args.no_long_run and not args.stub) else None
+
+    fixed = run_fixed_batch(eng, args.fixed_batch, world, rank, use_dist, sync_all) if args.fixed_batch > 0 else None
 
     if rank == 0:
         out = {
@@ -534,6 +701,11 @@ def worker(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "stub" if args.stub else ("synthetic (rehearsal: all ranks on one GPU)" if args.rehearse_on_one_gpu else "synthetic"),
         }
+        if dt_long is not None:
+            out["ms_per_step_%d" % LONG_STEPS] = dt_long / LONG_STEPS * 1e3
+            out["value_%d_steps" % LONG_STEPS] = world * LONG_STEPS * H * W / dt_long / 1e6
+        if fixed is not None:
+            out["fixed_batch"] = fixed
         if not args.stub:
             finish_report(out, eng, args, world)
         print(json.dumps(out), flush=True)
@@ -611,6 +783,29 @@ def other_configs(eng, args):
                                      "batched launch per phase" % BCD_TIMES,
                          "ms": best, "ms_mean": mean, "passes": 2, "Mpix/s": 2 * H * W / best / 1e3,
                          "dtype": "f32 descriptors / f32 distance / f64 DP"}
+    # low texture: the same configuration on a frame with saturated sky, a flat road band, blur and a repeated pattern
+    # (synth.py "low_texture"; real KITTI frames have these, daisy i flann.py:26-27,66): one pair alone on the GPU, next to the
+    # dense-texture pair measured the same way, and what the kNN screen did
+    lt1, lt2, _ = synth.make_pair(H, W, seed=eng.seeds[0], style="low_texture")
+    lt = (torch.from_numpy(lt1).to(dev), torch.from_numpy(lt2).to(dev))
+    one = dfs[:1]
+    dense_best, _ = timed(lambda: run_passes(one, [(a, b)], BCD_TIMES, streams[:1]))
+    lt_best, lt_mean = timed(lambda: run_passes(one, [lt], BCD_TIMES, streams[:1]))
+    lt_knn, _ = knn_kernel_times(torch, one[0], lt)
+    with torch.cuda.stream(streams[0]):
+        one[0].load_pair(*lt); one[0].generisi()
+        st = one[0].knn_stats()
+    res["low_texture"] = {"workload": "single 1024x436 pair, forward, bcd_times=%d, synth style low_texture (31 %% saturated = all-zero DAISY, 24 %% "
+                                      "road band of +-2 grey levels, blurred box, 16-px repeated pattern), one pair alone on the GPU" % BCD_TIMES,
+                          "ms_per_pass": lt_best, "ms_per_pass_mean": lt_mean, "dense_texture_ms_per_pass": dense_best,
+                          "ratio_to_dense_texture": lt_best / dense_best,
+                          "knn_kernels_ms": {k: round(v, 4) for k, v in lt_knn.items()},
+                          "events_per_query_cell": st["events_per_query_cell"], "lists": st["lists"],
+                          "lists_to_exact_search": st["lists_exact"], "whole_pass_fallback": bool(st["flags"] & 1),
+                          "max_entries_per_lane": st["max_entries_per_lane"], "list_capacity_per_lane": st["list_capacity"],
+                          "all_zero_queries": st["zero_queries"], "all_zero_candidates_removed": st["zero_candidates_removed"],
+                          "note": "round 3's screen sent this frame's whole pass to the brute-force kernel (knn_fix_kernel 81 ms, "
+                                  "profiles/r04_lowtex_round3_code.jsonl)"}
     # configs[4] geometry: 4 passes (2 pairs, both directions)
     kh, kw, kch, kcw, ksweeps = 375, 1242, 25, 54, 8
     kdfs = [pl.DiscreteFlow(kh, kw, kch, kcw, device=dev, seed=0, flags=_lib.FLAG_DESCR_F16) for _ in range(4)]
@@ -691,8 +886,8 @@ def finish_report(out, eng, args, world):
               "mfma_pipe_busy_frac_from_profiles": profile_scalar("knn_screen_kernel_mfma_busy_frac"),
               "note": "launch_ms = HIP events around the kernel on its launch stream (dflow_knn_proposals_timed), one pair alone on "
                       "the GPU, mean of 3; algorithmic flops = 2*68 per (query, candidate) pair of the +-2-cell windows (SURVEY 8(d)); "
-                      "issued = v_mfma_f32_32x32x16_f16 count x 32768 (two passes over the 42 leading principal components "
-                      "+ 6 bound slots, K = 48, padded tiles included)"}
+                      "issued = v_mfma_f32_32x32x16_f16 count x 32768 (two passes over the 40 leading principal components "
+                      "+ 8 bound slots, K = 48, padded tiles included)"}
     dominant = screen if screen["ms_per_step"] >= chain["ms_per_step"] else chain
     out["roofline"] = dict(dominant)
     out["roofline"]["dominant_by"] = "ms per step measured in this run: %s %.3f, %s %.3f" % (
@@ -700,6 +895,15 @@ def finish_report(out, eng, args, world):
     out["roofline"]["kernels"] = {"knn_screen_kernel": screen, "bcd_chain_kernel": chain}
     out["roofline"]["knn_kernels_ms"] = {k: round(v, 4) for k, v in knn_ms.items()}
     out["roofline"]["stages"] = stage_rooflines(torch, eng.flows[0], eng.pairs[0], eng.cellh, eng.cellw)
+    tot, top = total_traffic_per_pass()
+    alg = out["roofline"]["stages"]["end_to_end"]["bytes"]
+    out["roofline"]["total_traffic_per_pass"] = {"hbm_bytes": tot, "algorithmic_bytes": alg, "ratio": (tot / alg) if tot else None,
+                                                 "largest_kernels": top,
+                                                 "source": "sum over all kernels of profiles/pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE), per pass"}
+    stale, detail = profiles_state()
+    out["stale_profiles"] = stale
+    out["roofline"]["stale_profiles"] = stale
+    out["roofline"]["profiles_collected_with"] = detail
     out["latency_ms_single_pair"] = out["roofline"]["stages"]["ms_total"]
     out["latency_note"] = ("ms_per_step is pipelined throughput (%d pairs per group, two groups alternating); one pair alone on the GPU, "
                            "stage after stage on one stream, takes latency_ms_single_pair" % P)
@@ -712,6 +916,13 @@ def finish_report(out, eng, args, world):
     out["epe_delta_vs_oracle"] = None
     if world == 1 and not args.no_other_configs:
         out["other_configs"] = other_configs(eng, args)
+        if out.get("fixed_batch"):
+            # on 8 GPUs every rank has 2 of the 16 passes = the configs[2] case (one pair, both directions, on one GPU)
+            c3 = dict(out["fixed_batch"])
+            c3["projected_speedup_1_to_8_gpus"] = c3["ms"] / out["other_configs"]["configs[2]"]["ms"]
+            c3["projection_note"] = ("this run's %d-pass time / configs[2]'s time (2 passes on one GPU, what every rank of 8 has); the "
+                                     "measured curve is fixed_batch.ms of the runs with --gpus 1, 2, 4, 8" % c3["passes"])
+            out["other_configs"]["configs[3]"] = c3
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"], out["epe"], out["epe_delta_vs_oracle"] = cpu_baseline(eng.synth, gpu_flow, eng.seeds[0], eng.cellh, eng.cellw)
 
@@ -719,9 +930,10 @@ def finish_report(out, eng, args, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=98)       # 14 groups of 7: the fill and drain of the two-group pipeline weigh < 10 %
+    ap.add_argument("--steps", type=int, default=LONG_STEPS)       # 14 groups of 7: the fill and drain of the two-group pipeline weigh < 10 %
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long-run", action="store_true", help="skip the extra timed region of %d steps (ms_per_step_%d)" % (LONG_STEPS, LONG_STEPS))
     ap.add_argument("--no-other-configs", action="store_true", help="skip the one-GPU timings of BASELINE configs[2] and [4]")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent pairs in flight per GPU (each on its own HIP stream and workspace)")
@@ -732,6 +944,9 @@ def main():
     ap.add_argument("--front", type=int, default=3, help="HIP streams for the front end of a group in --mode batch")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks on device 0, gather over gloo (a multi-rank rehearsal on a one-GPU box; not a measurement)")
+    ap.add_argument("--fixed-batch", type=int, default=16,
+                    help="passes of the fixed batch run after the timed steps (BASELINE configs[3]: 8 pairs x 2 directions, pass p -> rank "
+                         "p mod N: strong scaling, reported under fixed_batch); 0: skip")
     ap.add_argument("--groups", default=None, help=argparse.SUPPRESS)    # experiment: explicit group sizes of the timed region
     ap.add_argument("--no-lists-stream", action="store_true", help=argparse.SUPPRESS)   # experiment: compat lists on the BCD stream itself
     ap.add_argument("--lists-on-front", action="store_true", help=argparse.SUPPRESS)    # experiment: compat lists on the front-end streams (before round 3: the default)

@@ -102,6 +102,17 @@ int dflow_knn_proposals_timed(const dflow_params *p, const void *d_descr1, const
                               uint32_t *d_proposals, float *d_lcosts, int32_t *d_nprop, int32_t *d_bestlabels,
                               void *d_ws, size_t ws_bytes, void *stream, float *h_ms, double *h_mfma_issued);
 
+/* Measurement aid (bench.py's other_configs, the low-texture tests): what the MFMA screen of the LAST dflow_knn_proposals call on
+ * this workspace did, read back from the workspace (WAITS for the stream; call it before another stage reuses the workspace).
+ * h_stats[DFLOW_KNN_STATS_N] (host): [0] event lists handed to the exact brute-force search (rows outside the f16 range / NaN),
+ * [1] flags (bit 0: the whole pass went to the exact search: the basis failed its orthonormality check), [2] event lists of the
+ * pass, [3] list entries written, [4] events = (query, candidate) pairs evaluated exactly, [5] most entries in one lane's list,
+ * [6] all-zero queries (answered from their cells' own lists), [7] queries outside the screen's range, [8] all-zero candidate
+ * rows, [9] of those removed as duplicates, [10] (query, cell) pairs of the pass, [11] list capacity per lane.
+ * No reference counterpart. */
+#define DFLOW_KNN_STATS_N 12
+int dflow_knn_screen_stats(const dflow_params *p, void *d_ws, size_t ws_bytes, void *stream, int64_t *h_stats);
+
 /* nasumicni, daisy i flann.py:205-233: appends up to ngauss neighbour proposals per pixel (in place).
  * d_bestlabels must still hold the WTA labels written by dflow_knn_proposals.  Uses 4 bytes per pixel of the workspace
  * (the WTA flow of every pixel, gathered once). */

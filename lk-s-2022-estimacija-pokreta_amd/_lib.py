@@ -9,7 +9,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libdflow.so")
 
 SYMBOLS = ("dflow_version", "dflow_last_error", "dflow_default_params", "dflow_workspace_bytes", "dflow_daisy",
-           "dflow_knn_proposals", "dflow_knn_proposals_timed", "dflow_neighbour_proposals", "dflow_bcd_prepare", "dflow_bcd_phase", "dflow_bcd_sweep",
+           "dflow_knn_proposals", "dflow_knn_proposals_timed", "dflow_knn_screen_stats", "dflow_neighbour_proposals", "dflow_bcd_prepare", "dflow_bcd_phase", "dflow_bcd_sweep",
            "dflow_bcd_phase_batch", "dflow_bcd_sweep_batch",
            "dflow_labels_to_flow", "dflow_fb_consistency", "dflow_pack_compat", "dflow_remove_small_segments_host")
 
@@ -58,6 +58,7 @@ def lib():
         L.dflow_daisy.argtypes = [pp, vp, vp, vp, sz, vp]
         L.dflow_knn_proposals.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.dflow_knn_proposals_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.dflow_knn_screen_stats.argtypes = [pp, vp, sz, vp, C.POINTER(C.c_int64)]
         L.dflow_neighbour_proposals.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.dflow_bcd_prepare.argtypes = [pp, vp, vp, vp, vp, sz, vp]
         L.dflow_bcd_phase.argtypes = [pp, vp, vp, vp, i32, vp, sz, vp]

@@ -117,6 +117,16 @@ int dflow_knn_proposals_timed(const dflow_params *p, const void *d_descr1, const
     return rc;
 }
 
+int dflow_knn_screen_stats(const dflow_params *p, void *d_ws, size_t ws_bytes, void *stream, int64_t *h_stats)
+{
+    int rc = dflow_check_params(p); if (rc) return rc;
+    CHECK_PTR(h_stats);
+    if ((p->flags & DFLOW_FLAG_KNN_EXACT) || !knn_mfma_supported(p))
+        return dflow_set_error(DFLOW_EINVAL, "%s: the MFMA-screened search does not run for these parameters", __func__);
+    CHECK_WS(knn_mfma_ws_bytes(p));
+    return knn_mfma_stats(p, d_ws, (hipStream_t)stream, h_stats);
+}
+
 int dflow_neighbour_proposals(const dflow_params *p, const void *d_descr1, const void *d_descr2, uint32_t *d_proposals,
                               float *d_lcosts, int32_t *d_nprop, const int32_t *d_bestlabels, void *d_ws, size_t ws_bytes,
                               void *stream)

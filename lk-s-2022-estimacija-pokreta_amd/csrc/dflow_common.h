@@ -138,6 +138,7 @@ int launch_knn(const dflow_params *p, const void *d1, const void *d2, uint32_t *
 int launch_knn_mfma(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,
                     int32_t *nprop, int32_t *bestlabels, void *ws, hipStream_t s, hipEvent_t *ev = nullptr);
 double knn_mfma_issued(const dflow_params *p);
+int knn_mfma_stats(const dflow_params *p, void *ws, hipStream_t s, int64_t *h_out);
 size_t knn_mfma_ws_bytes(const dflow_params *p);
 bool knn_mfma_supported(const dflow_params *p);
 int launch_neighbour(const dflow_params *p, const void *d1, const void *d2, uint32_t *proposals, float *lcosts,

@@ -4,37 +4,49 @@
 // bit for bit -- but the 1.7e10 descriptor pairs of a Sintel pass are screened by f16 MFMA instead of being
 // evaluated one by one:
 //
-//   basis     a fixed centre mu (mean descriptor of a pixel sample, knn_mean_kernel) and the principal axes V of a sample
-//             of image-2 descriptors (knn_pca.hip).  x = 64 (d - mu), y = V^T x: distances do not change
-//             (V orthonormal to 2e-6, measured), the products get smaller, and the energy of y collects in its leading
-//             components: the screen multiplies the first KM_KD = 42 of them (y_P) and bounds the product of the dropped 26
-//             (y_D) by Cauchy-Schwarz, |y_D(q) . y_D(c)| <= n_q n_c with n >= |y_D|.
-//   prep      (knn_prep_kernel) both images become rows of KM_K = 48 f16: y~ = f16(y_P), then for image 2 n_c, two f16
-//             pieces of h = 0.5 |x_c|^2, the candidate's share S_c of the error bound and two 1.0; for image 1 n_q and the
-//             matching selectors.  With G^ = the MFMA's value of y~_q . y~_c (exact products, f32 accumulation) and
-//             E = y~ - y_P the rounding errors actually made (the f16 part is measured, nothing is assumed about f16
-//             rounding; the float32 rotation enters with its worst-case bound KM_RHO |x|),
-//                 |y_P(q) . y_P(c) - G^| <= |y~_q||E_c| + |E_q||y_P(c)| + eta (sum of |products|)  <=  S_c + S_q,
-//                 S_c = |E_c|^2/(2t) + (t/2)|y_P(c)|^2 + eta (|y~_c|^2/2 + n_c^2/2 + h) + 2e-6 h,
-//                 S_q = (t/2)|y~_q|^2 + |E_q|^2/(2t) + (eta/2)(|y~_q|^2 + n_q^2)
-//             (t = 2^-12.5; eta = 2^-17 bounds the f32 accumulation of the 48 exact products inside the matrix core: it
-//             holds for ANY order of the additions and any rounding mode with at most one ulp (2^-23) per addition, up to 64
-//             terms; measured on gfx950, scratch/ubench/mfma_err.hip: <= 2^-20.7 at K = 80 over six operand distributions;
-//             2e-6 h covers the two-piece representation of h, |V^T V - I| and the float32 rounding of d - mu), so tau = y_q . y_c - 0.5 |y_c|^2 = 0.5 (|y_q|^2 - |y_q - y_c|^2) lies within
-//             n_q n_c + S_c + S_q of G^ - h.
-//   screen    (knn_screen_kernel) pass 1: w = G^ - n_q n_c - h - S_c for every (query, candidate) of a (64-query wave,
-//             candidate cell); w - S_q <= tau.  Every lane keeps the 5 largest maxima of its 16-value tile columns -> a5,
-//             and a5 - S_q is a lower bound of the 5th largest tau of the query.  pass 2: v = G^ + n_q n_c - h + S_c;
-//             v + S_q >= tau.  Only candidates with v >= a5 - 2 S_q - s (s: rounding of the canonical float32 distance)
-//             can be among the exact 5 NN: these "events" (a 16-bit row mask per lane and tile) go to per-lane lists in
-//             the workspace.  Events per (query, cell) on the bench frame: 5.7 (5 is the minimum; all 68 dimensions in
-//             the product, 5 MFMAs per tile instead of 3, gave 5.5).
+//   basis     the principal axes V of the second-moment matrix (about the ORIGIN) of a sample of image-2 descriptors
+//             (knn_pca.hip).  x = 64 d, y = V^T x: distances do not change (V orthonormal to 2e-6, measured), and the energy
+//             of y collects in its leading components: the screen multiplies the first KM_KD = 40 of them (y_P) and bounds
+//             the product of the dropped 28 (y_D) by Cauchy-Schwarz, |y_D(q) . y_D(c)| <= n_q n_c with n >= |y_D|.
+//             No centring (rounds 2-3 subtracted the mean descriptor): DAISY without normalisation (daisy i flann.py:66) is a
+//             gradient histogram, so the descriptors of low-texture regions (road, sky, blur) cluster at the ORIGIN, and f16
+//             keeps its 11 bits on them only if the origin stays where it is (tools/screen_model.py: a road pixel against a
+//             road cell emits 95 events with the mean as centre, 6 with the origin).
+//   prep      (knn_prep_kernel) both images become rows of KM_K = 48 f16: y~ = f16(y_P), then the row's factors of the
+//             bound.  With G^ = the MFMA's value of y~_q . y~_c (exact products, f32 accumulation) and E = y~ - y_P the
+//             rounding errors actually made (the f16 part is measured, nothing is assumed about f16 rounding, subnormals
+//             included; the float32 rotation enters with its worst-case bound KM_RHO |x|),
+//                 y_P(q) . y_P(c) = y~_q . y~_c - y~_q . E_c - E_q . y_P(c)
+//                 |y_P(q) . y_P(c) - G^| <= |y~_q| (|E_c| + eta |y~_c|) + |E_q| |y_P(c)| + eta (other products)
+//             and every term is a product of a per-query and a per-candidate number, i.e. ONE K slot of the same MFMA
+//             (rounds 2-3 split the cross terms by AM-GM into S_q + S_c with a fixed t = 2^-12.5, which is loose by
+//             |y_q| / |y_c| when a textured query meets a flat cell).  eta = 2^-17 bounds the f32 accumulation of the 48
+//             exact products inside the matrix core: it holds for ANY order of the additions and any rounding mode with at
+//             most one ulp (2^-23) per addition, up to 64 terms; measured on gfx950, tools/ubench/mfma_err.hip: <= 2^-20.7
+//             at K = 80 over six operand distributions.  Candidate rows: [y~(40), n_c, 64 (|E_c| + eta |y~_c|), |y_P(c)| / 64,
+//             two f16 pieces of h = 0.5 |x_c|^2, 4096 S_c, 1, 1] with S_c = eta h + 3e-6 h + the measured residual of the
+//             two pieces (3e-6 h covers |V^T V - I| and the roundings); query rows: [y~(40), -+n_q, -+|y~_q| / 64,
+//             -+64 |E_q|, -1, -1, -+2^-12, -th_1, -th_2]; all bound factors rounded UP into f16.  So tau = y_q . y_c -
+//             0.5 |y_c|^2 = 0.5 (|y_q|^2 - |y_q - y_c|^2) lies between the two values one MFMA chain yields:
+//   screen    (knn_screen_kernel) pass 1: w = G^ - bounds - h - S_c <= tau for every (query, candidate) of a (64-query wave,
+//             candidate cell).  Every lane keeps the 5 largest maxima of its 16-value tile columns -> a5 <= the 5th largest
+//             tau of the query.  pass 2: v = G^ + bounds - h + S_c >= tau.  Only candidates with v >= a5 - s (s: rounding
+//             of the canonical float32 distance) can be among the exact 5 NN: these "events" (a 16-bit row mask per lane
+//             and tile) go to per-lane lists in the workspace (capacity = the tiles of a cell: a list cannot overflow).
+//             Events per (query, cell) on the bench frame: 5.7 (5 is the minimum).
+//   hard rows candidate rows that are all zero (saturated / constant regions: exactly-zero DAISY) tie with each other for
+//             every query, and the canonical order breaks ties by index: only the 5 of lowest index in a cell can enter
+//             a top 5, the others become sentinel rows (knn_cell_post_kernel).  An all-zero QUERY has the same answer in a
+//             cell wherever it is (distance = |c|^2): the 5 candidates of smallest (|c|^2, index), found once per cell
+//             (knn_cell_post_kernel) and copied by the resolve kernel; such lanes emit no events.
 //   resolve   (knn_resolve_kernel) one wave per (64 queries, window column): canonical float32 distance (sequential
 //             fmaf chain) and truncated L1 cost (numpy order) of every event, exact (distance, index) top-5 in
 //             registers, proposals [dy,dx] and costs into the cell's 5 slots (Q1-Q3).  The rows are fetched by the
 //             whole wave through LDS (see the kernel).
-//   fix       lists that overflowed (or a pass with descriptors outside the f16 range / NaN) are redone by the exact
-//             brute-force search (knn.hip).  finalize sets nprop, the WTA label (first minimum, Q4) and the fills.
+//   fix       lists that cannot be screened (a query or candidate outside the range the f16 rows cover, NaN: flagged per
+//             LIST by the prep kernel) are redone by the exact brute-force search (knn.hip), list by list -- never the whole
+//             pass, unless the basis itself fails its orthonormality check.  finalize sets nprop, the WTA label (first
+//             minimum, Q4) and the fills.
 //
 // MFMA layout (v_mfma_f32_32x32x16_f16): A = candidates (rows), B = queries (columns): lane l holds
 // A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31]; D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5).
@@ -51,11 +63,17 @@ template <int V> struct KmC { static constexpr int value = V; };
 #define KM_ALPHA 64.0f
 #define KM_K 48                 // f16 per prepared row (96 bytes)
 #define KM_KSTEPS (KM_K / 16)   // MFMAs per 32x32 tile
-#define KM_KD 42                // leading principal components in the matrix product
-#define KM_SLOT_N 42            // n = bound of the norm of the dropped components
+#define KM_KD 40                // leading principal components in the matrix product
+#define KM_SLOT_N 40            // n = bound of the norm of the dropped components (queries: -n in pass 1, +n in pass 2)
+#define KM_SLOT_QE 41           // candidates: 64 (|E_c| + eta |y~_c|); queries: -+|y~_q| / 64
+#define KM_SLOT_EN 42           // candidates: |y_P(c)| / 64; queries: -+64 |E_q|
 #define KM_SLOT_H 43            // 43, 44: two f16 pieces of h (candidates) / -1, -1 (queries)
-#define KM_SLOT_S 45            // S_c (candidates) / -1 in pass 1, +1 in pass 2 (queries)
+#define KM_SLOT_S 45            // 4096 S_c (candidates) / -2^-12 in pass 1, +2^-12 in pass 2 (queries)
 #define KM_SLOT_ONE 46          // 46, 47: 1.0 (candidates) / minus the two pieces of the threshold in pass 2 (queries)
+#define KM_XSCALE 64.0          // scaling of the two cross-term slot pairs (keeps both factors in f16's normal range)
+#define KM_SSCALE 4096.0        // scaling of the S_c slot
+#define KM_NORM2_MAX 30000.0    // rows with |x|^2 beyond this are not screened (their lists go to the exact search): with both
+                                // norms below it every real MFMA value lies above -50000 and the sentinel rows (-60000) below
 #define KM_WAVES 8
 #define KM_THREADS (64 * KM_WAVES)
 #define KM_QPW 64               // queries per wave: 2 column groups of 32
@@ -72,14 +90,13 @@ template <int V> struct KmC { static constexpr int value = V; };
 #endif
 #define KM_MAXNW ((KM_STAGE_INS + KM_WAVES - 1) / KM_WAVES)     // DMA instructions of a wave per chunk: KM_MAXNW or one fewer
 #define KM_SPC (2 * (KM_CHUNK / 32))                           // event stores of a wave per chunk in pass 2 (tiles x groups)
-#define KM_EVROWS_MAX 32        // event entries (tile, 16-bit row mask) per lane, group and candidate cell (mean 2.7, 99 % <= 7; a list
-                                // that runs out is redone by knn_fix_kernel): 32, 24 or 16, the largest that keeps the kNN stage's
-                                // scratch below what the BCD stage needs anyway (km_evrows)
+#define KM_EVROWS_MAX 96        // event entries (tile, 16-bit row mask) per lane, group and candidate cell: one per tile of the largest
+                                // cell + 1 (km_evrows), so that no list can run out (mean 2.7, 99 % <= 7 on dense texture, but every
+                                // tile of a cell in flat regions); cells of more than 95 tiles (3040 points): 96, and a list
+                                // that does run out is redone by knn_fix_kernel
 #define KM_MAXPTS 65535         // candidate index must fit 16 bits
 #define KM_LIST_WORDS(evrows) (2 * (evrows) * 64)       // one event list: [group][entry][lane] uint32
-#define KM_T 1.7263349e-4                        // t = 2^-12.5: split of the cross terms |y~_q||E_c|, |E_q||y_c| (see header)
 #define KM_ETA 7.62939453125e-6                  // eta = 2^-17: allowance for the f32 accumulation inside the matrix core
-#define KM_MEAN_SAMPLES 1024
 
 struct KmGeom {
     Geom g;
@@ -113,44 +130,41 @@ __host__ __device__ static inline size_t km_total_rows(const Geom &g)
     return km_cell_base(g, 0, g.ncy - 1) + (size_t)(g.ncx - 1) * km_pad(g.cw * hl) + km_pad(wl * hl);
 }
 
-// mu = mean descriptor over KM_MEAN_SAMPLES (1024: the single block is latency-bound) evenly spaced pixels of image 2: one block, thread = (dimension, sample group),
-// partial sums combined in a fixed order.  Any mu gives exact results; a good one makes the screen tight.
-template <typename T>
-__global__ void __launch_bounds__(1024) knn_mean_kernel(const T *__restrict__ d, float *__restrict__ mu, int npix)
+// the row of a position without a candidate: h = 60000, everything else 0 -> MFMA value -60000 in both passes, below every
+// real one (rows the screen accepts lie above -50000, KM_NORM2_MAX) and below every threshold (>= -55000; no 1.0 here to subtract it)
+__device__ static inline void km_store_sentinel(_Float16 *row)
 {
-    __shared__ float part[15][DFLOW_DESC];
-    const int k = threadIdx.x % DFLOW_DESC, grp = threadIdx.x / DFLOW_DESC;
-    const int nsamp = npix < KM_MEAN_SAMPLES ? npix : KM_MEAN_SAMPLES, stride = npix / nsamp;
-    if (grp < 15) {
-        float acc = 0.0f;
-        for (int sidx = grp; sidx < nsamp; sidx += 15) acc += (float)d[(size_t)sidx * stride * DescPitch<T>::value + k];
-        part[grp][k] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < DFLOW_DESC) {
-        float acc = 0.0f;
-        for (int j = 0; j < 15; j++) acc += part[j][threadIdx.x];
-        const float m = acc / (float)nsamp;
-        mu[threadIdx.x] = (__float_as_uint(m) & 0x7FFFFFFFu) < 0x7F800000u ? m : 0.0f;    // NaN/inf in the sample: centre 0
-    }
+    half8 *o = reinterpret_cast<half8 *>(row);
+    const half8 z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    half8 t8 = z;
+    t8[KM_SLOT_H - 40] = (_Float16)60000.0f;
+#pragma unroll
+    for (int k = 0; k < KM_K / 8; k++) o[k] = k == KM_K / 8 - 1 ? t8 : z;
 }
 
 // f16 value not below v (v >= 0, below the f16 range): the factor exceeds one half-ulp of the rounding to nearest, the
 // constant the spacing of the subnormals
 __device__ static inline _Float16 km_f16_up(double v) { return (_Float16)(float)(v * 1.001 + 1e-7); }
 
+// per-pixel record of image 1 next to its f16 row
+#define KM_Q_ZERO 1.0f          // the descriptor is all zero: the answer of every cell comes from the cell's own list (KmCellTop)
+#define KM_Q_BAD 2.0f           // outside the range the screen covers (or NaN): every list of its 64-query wave goes to the exact search
+// per-position record of image 2: canonical squared norm (= the canonical distance of an all-zero query) and |c|_1 in numpy's
+// summation order (= its L1 cost), so that the all-zero queries' answer can be found once per cell
+struct KmCellTop { uint32_t idx[5]; float cost[5]; };
+
 // which = 0: image 1 (queries), one thread per pixel, rows in pixel order.  which = 1: image 2 (candidates), one thread
 // per (cell = blockIdx.y, tile position), rows in position order (above).  The rotation y_j = sum_i V[j][i] x_i runs as two
 // float32 fmaf chains (even / odd dimensions: one chain of packed fmas) that are added at the end; the components of V arrive
 // through the scalar cache (vt is wave-uniform), 8 components per iteration = one 16-byte store.  Its rounding is part of E:
-// for ANY order of the 68 additions |y^_j - y_j| <= gamma_68 sum_i |V_ji x_i| <= 68 * 2^-24 (1 + 5e-6) |x|, over the 42
-// components |y^ - y_P| <= 2.63e-5 |x| (KM_RHO also holds the 6.2e-8 |x| of the rounding of d - mu).
+// for ANY order of the 68 additions |y^_j - y_j| <= gamma_68 sum_i |V_ji x_i| <= 68 * 2^-24 (1 + 5e-6) |x|, over the 40
+// components |y^ - y_P| <= 2.57e-5 |x| (KM_RHO; x = 64 d is exact).
 #define KM_RHO 2.65e-5
 typedef float km_f2p __attribute__((ext_vector_type(2)));
 template <typename T>
-__global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, const float *__restrict__ mu,
-                                                       const float *__restrict__ vt, _Float16 *__restrict__ h,
-                                                       float2 *__restrict__ qs, int *__restrict__ flags, Geom g, int which)
+__global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, const float *__restrict__ vt, _Float16 *__restrict__ h,
+                                                       float2 *__restrict__ qs, float2 *__restrict__ z0, uint8_t *__restrict__ zflag,
+                                                       int *__restrict__ cell_bad, Geom g, int which)
 {
     int pix;
     size_t orow;
@@ -167,29 +181,43 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, 
         const int ntiles = km_pad(cnpts) / 32;
         const int idx = (pos & 31) * ntiles + (pos >> 5);
         if (idx >= cnpts) {
-            // no candidate here: h = 60000, everything else 0 -> MFMA value -60000 in both passes, below every real one
-            // (real h +- S_c lie inside +-50000) and below every threshold (>= -55000; no 1.0 here to subtract it)
-            half8 *o = reinterpret_cast<half8 *>(h + orow * KM_K);
-            half8 z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
-            half8 t8 = z;
-            t8[KM_SLOT_H - 40] = (_Float16)60000.0f;
-            for (int k = 0; k < KM_K / 8; k++) o[k] = k == 5 ? t8 : z;
+            km_store_sentinel(h + orow * KM_K);
+            z0[orow] = make_float2(INFINITY, 0.0f);
+            zflag[orow] = 0;
             return;
         }
         pix = (cy0 + idx / ccw) * g.W + cx0 + idx % ccw;
     }
     float x[DFLOW_DESC];
     desc_load_row(x, d, (size_t)pix);
+    if (which == 1) {
+        // what an all-zero query would compute for this candidate: e = 0 - c_k, acc = fmaf(e, e, acc) over k = 0..67, and
+        // sum |e| in numpy's pairwise order (knn_resolve_kernel, l1_cost_np)
+        float acc = 0.0f, rs[8];
+#pragma unroll
+        for (int k = 0; k < DFLOW_DESC; k++) acc = __fmaf_rn(x[k], x[k], acc);
+#pragma unroll
+        for (int j = 0; j < 8; j++) rs[j] = fabsf(x[j]);
+#pragma unroll
+        for (int i = 8; i < 64; i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; j++) rs[j] = rs[j] + fabsf(x[i + j]);
+        float l1 = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+#pragma unroll
+        for (int i = 64; i < DFLOW_DESC; i++) l1 = l1 + fabsf(x[i]);
+        z0[orow] = make_float2(acc, l1);
+    }
     double sxall = 0.0;
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < DFLOW_DESC; k++) {
-        const float sc = KM_ALPHA * (x[k] - mu[k]);   // one rounding (the subtraction); the scaling is exact
-        // too large or NaN (tested on the bits: this file is compiled with -fno-honor-nans): no f16 representation
-        bad |= (__float_as_uint(sc) & 0x7FFFFFFFu) >= 0x476A6000u;      // |sc| >= 60000, inf, NaN
+        const float sc = KM_ALPHA * x[k];             // exact
+        bad |= (__float_as_uint(sc) & 0x7FFFFFFFu) >= 0x7F800000u;      // inf, NaN (tested on the bits: -fno-honor-nans)
         x[k] = sc;
         sxall = fma((double)sc, (double)sc, sxall);          // |x|^2; |V^T x|^2 = |x|^2 (1 +- PCA_DELTA_MAX)
     }
+    bad |= !(sxall < KM_NORM2_MAX);
+    const bool zero = sxall == 0.0;                   // every value +-0: ties with every other such row for every query
     double ss = 0.0, sx = 0.0, se = 0.0;        // |y~|^2, |y^|^2, |y~ - y^|^2 over the KM_KD leading components
     auto component = [&](int j) -> _Float16 {
         // two fmaf chains (even / odd dimensions) as ONE chain of v_pk_fma_f32: half the instructions of a single chain
@@ -198,13 +226,13 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, 
 #pragma unroll
         for (int i = 0; i < DFLOW_DESC / 2; i++) acc = __builtin_elementwise_fma(vj[i], (km_f2p){x[2 * i], x[2 * i + 1]}, acc);
         const float y = acc.x + acc.y;
-        bad |= (__float_as_uint(y) & 0x7FFFFFFFu) >= 0x476A6000u;
         const _Float16 hv = (_Float16)y;
         const double f = (double)(float)hv, yd = (double)y, er = f - yd;
         ss = fma(f, f, ss); sx = fma(yd, yd, sx); se = fma(er, er, se);
         return hv;
     };
     half8 *o = reinterpret_cast<half8 *>(h + orow * KM_K);
+    static_assert(KM_KD % 8 == 0 && KM_KD + 8 == KM_K, "the last 16-byte piece of a row holds the eight bound slots");
 #pragma unroll 1
     for (int jo = 0; jo < KM_KD / 8; jo++) {
         half8 r;
@@ -213,46 +241,113 @@ __global__ void __launch_bounds__(256) knn_prep_kernel(const T *__restrict__ d, 
         o[jo] = r;
     }
     half8 last;
-#pragma unroll
-    for (int j = 8 * (KM_KD / 8); j < KM_KD; j++) last[j - 8 * (KM_KD / 8)] = component(j);
-    // E = y~ - y_P: |E| <= |y~ - y^| + KM_RHO |x|;  |y_P| <= |y^| + KM_RHO |x|;
+    // |E| <= |y~ - y^| + KM_RHO |x|;  |y_P| <= |y^| + KM_RHO |x|;
     // |y_D|^2 = |y|^2 - |y_P|^2 <= (1 + delta)|x|^2 - (|y^| - KM_RHO |x|)^2
     const double rx = sqrt(sxall), ry = sqrt(sx);
-    double ee = sqrt(se) + KM_RHO * rx;
-    ee = ee * ee;
+    const double en = sqrt(se) + KM_RHO * rx;
     const double ypl = fmax(0.0, ry - KM_RHO * rx), ypu = ry + KM_RHO * rx;
     const double nd = sqrt(fmax(0.0, sxall * (1.0 + 1.1 * PCA_DELTA_MAX) - ypl * ypl));
-    const _Float16 n16 = km_f16_up(nd);
-    const double nn = (double)(float)n16;
-    last[KM_SLOT_N - 40] = n16;
+    // km_f16_up exceeds its argument by >= 5e-4 relative: that also pays the accumulation allowance eta on the slot's own product
     if (which == 0) {
+        // stored in pass-1 form (all bound terms subtracted); the screen flips the four signs for pass 2
+        last[KM_SLOT_N - 40] = -km_f16_up(nd);
+        last[KM_SLOT_QE - 40] = -km_f16_up(sqrt(ss) * (1.0 / KM_XSCALE));
+        last[KM_SLOT_EN - 40] = -km_f16_up(en * KM_XSCALE);
         last[KM_SLOT_H - 40] = (_Float16)-1.0f; last[KM_SLOT_H + 1 - 40] = (_Float16)-1.0f;
-        last[KM_SLOT_S - 40] = (_Float16)-1.0f;
+        last[KM_SLOT_S - 40] = (_Float16)(float)(-1.0 / KM_SSCALE);
         last[KM_SLOT_ONE - 40] = (_Float16)0.0f; last[KM_SLOT_ONE + 1 - 40] = (_Float16)0.0f;
-        // S_q and 0.5 |y_q|^2 (upper bounds, rounded up into float32)
-        const double sq = 0.5 * KM_T * ss + ee * (0.5 / KM_T) + 0.5 * KM_ETA * (ss + nn * nn);
-        qs[pix] = make_float2((float)(sq * 1.000001 + 1e-30), (float)(0.5 * sxall * (1.0 + 1.5 * PCA_DELTA_MAX)));
+        // (flag, 0.5 |y_q|^2 rounded up into float32)
+        qs[pix] = make_float2(bad ? KM_Q_BAD : zero ? KM_Q_ZERO : 0.0f, (float)(0.5 * sxall * (1.0 + 1.5 * PCA_DELTA_MAX) * 1.0000002));
     } else {
         const double hh = 0.5 * sxall;
-        // S_c (upper bound); the factor also covers eta S_c (the accumulation allowance is on every product, S_c's too);
-        // 3e-6 h: |0.5 |y_c|^2 - h| <= delta h, the float32 rounding of d - mu (1.2e-7 h) and the two-piece form of h (2.4e-7 h)
-        const double scs = (ee * (0.5 / KM_T) + 0.5 * KM_T * ypu * ypu + KM_ETA * (0.5 * ss + 0.5 * nn * nn + 1.001 * hh) + 3e-6 * hh) * 1.0004 + 1e-6;
-        const _Float16 s16 = km_f16_up(scs);
-        bad |= !(hh + (double)(float)s16 < 50000.0);
         const _Float16 p1 = (_Float16)(float)hh;
         const _Float16 p2 = (_Float16)(float)(hh - (double)(float)p1);
+        const double hres = fabs(hh - (double)(float)p1 - (double)(float)p2);     // what the two pieces miss (exact in double)
+        // S_c: eta on the h products (|p1| + |p2| <= 1.001 h) and on S_c's own; 3e-6 h: |0.5 |y_c|^2 - h| <= delta h;
+        // the measured residual of the two-piece form
+        const double scs = (KM_ETA * 1.001 * hh + 3e-6 * hh + hres) * 1.0004;
+        last[KM_SLOT_N - 40] = km_f16_up(nd);
+        last[KM_SLOT_QE - 40] = km_f16_up((en + KM_ETA * sqrt(ss)) * KM_XSCALE);
+        last[KM_SLOT_EN - 40] = km_f16_up(ypu * (1.0 / KM_XSCALE));
         last[KM_SLOT_H - 40] = p1; last[KM_SLOT_H + 1 - 40] = p2;
-        last[KM_SLOT_S - 40] = s16;
+        last[KM_SLOT_S - 40] = km_f16_up(scs * KM_SSCALE);
         last[KM_SLOT_ONE - 40] = (_Float16)1.0f; last[KM_SLOT_ONE + 1 - 40] = (_Float16)1.0f;
+        zflag[orow] = zero ? 1 : 0;
+        if (bad) cell_bad[blockIdx.y] = 1;
     }
     o[KM_K / 8 - 1] = last;
-    if (bad) atomicOr(flags, 1);
+}
+
+// One block per candidate cell, after knn_prep_kernel: (a) of the all-zero rows of the cell only the 5 of lowest index stay
+// candidates (equal rows have equal distances to every query and the canonical order prefers the lower index), the others
+// become sentinel rows; (b) the cell's answer for an all-zero query: the 5 candidates of smallest (|c|^2, index) with their
+// L1 costs, in that order (what knn_resolve_kernel would find).
+__global__ void __launch_bounds__(256) knn_cell_post_kernel(_Float16 *__restrict__ h2, const float2 *__restrict__ z0,
+                                                            const uint8_t *__restrict__ zflag, KmCellTop *__restrict__ ztop, Geom g)
+{
+    __shared__ int wsum[4];
+    __shared__ unsigned long long wmin[4];
+    const int ci = blockIdx.x % g.ncx, cj = blockIdx.x / g.ncx;
+    const int cnpts = (g.x1(ci) - g.x0(ci)) * (g.y1(cj) - g.y0(cj));
+    const int npad = km_pad(cnpts), ntiles = npad / 32;
+    const size_t base = km_cell_base(g, ci, cj);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int running = 0;
+    for (int c0 = 0; c0 < cnpts; c0 += 256) {                            // block-uniform trip count
+        const int idx = c0 + tid;
+        const int pos = (idx % ntiles) * 32 + idx / ntiles;
+        const bool z = idx < cnpts && zflag[base + pos] != 0;
+        const unsigned long long bal = __ballot(z);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = running + __popcll(bal & ((1ull << lane) - 1ull));
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { before += w < wave ? wsum[w] : 0; total += wsum[w]; }
+        if (z && before >= 5) km_store_sentinel(h2 + (base + pos) * KM_K);
+        running += total;
+        __syncthreads();
+    }
+    // (b): every thread keeps the 5 smallest keys of its positions, then 5 rounds of a block-wide minimum above the last winner
+    unsigned long long k5[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) k5[i] = ~0ull;
+    for (int pos = tid; pos < npad; pos += 256) {
+        const int idx = (pos & 31) * ntiles + (pos >> 5);
+        const float dd = z0[base + pos].x;
+        if (idx < cnpts && dd < INFINITY) {
+            unsigned long long x = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)idx;
+#pragma unroll
+            for (int i = 0; i < 5; i++) { const bool lt = x < k5[i]; const unsigned long long lo = lt ? x : k5[i]; x = lt ? k5[i] : x; k5[i] = lo; }
+        }
+    }
+    unsigned long long last = 0ull;
+    bool first = true;
+    for (int r = 0; r < 5; r++) {
+        unsigned long long m = ~0ull;
+#pragma unroll
+        for (int i = 4; i >= 0; i--) if (first || k5[i] > last) m = k5[i];              // smallest of mine above the last winner
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(m, off); m = o < m ? o : m; }
+        if (lane == 0) wmin[wave] = m;
+        __syncthreads();
+        m = wmin[0];
+#pragma unroll
+        for (int w = 1; w < 4; w++) m = wmin[w] < m ? wmin[w] : m;
+        if (tid == 0) {
+            const uint32_t idx = m == ~0ull ? 0u : (uint32_t)(m & 0xFFFFFFFFu);       // fewer than 5 finite rows: the cell is flagged bad
+            ztop[blockIdx.x].idx[r] = idx;
+            ztop[blockIdx.x].cost[r] = z0[base + (idx % ntiles) * 32 + idx / ntiles].y;
+        }
+        last = m; first = false;
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ screen
 struct KmScreen {
     const _Float16 *h1, *h2;       // prepared f16 rows
-    const float2 *qs;              // (S_q, 0.5 |q|^2) per image-1 pixel
+    const float2 *qs;              // (KM_Q_* flag, 0.5 |x_q|^2) per image-1 pixel
+    const int *cell_bad;           // per candidate cell: holds a row the screen does not cover
     uint32_t *ev;                  // [list][2][evrows][64]: (tile << 16) | row mask
     uint8_t *ev_cnt;               // [list][2][64]; 255 = overflow
 };
@@ -314,7 +409,8 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 
     // ---- my queries: group gq (0/1), column col; B fragments (last k-step differs between the passes) and slack
     half8 bfrag[2][KM_KSTEPS];
-    float sq[2], hq[2];
+    float hq[2];
+    bool qzero[2], qbad = false;
 #pragma unroll
     for (int gq = 0; gq < 2; gq++) {
         int qi = qwave * KM_QPW + gq * 32 + col;
@@ -323,12 +419,15 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         const half8 *src = reinterpret_cast<const half8 *>(p.h1 + (size_t)qpix * KM_K);
 #pragma unroll
         for (int s = 0; s < KM_KSTEPS; s++) bfrag[gq][s] = src[2 * s + half];
-        // k = 40..47 sit in half 1 of the last k-step: y40, y41, n_q, -1, -1 (h), -1 (S_c), 0, 0 as stored.  Pass 1
-        // computes G^ - n_q n_c - h - S_c: the n slot changes sign
-        if (half == 1) bfrag[gq][KM_KSTEPS - 1][KM_SLOT_N - 40] = -bfrag[gq][KM_KSTEPS - 1][KM_SLOT_N - 40];
+        // k = 40..47 sit in half 1 of the last k-step: -n_q, -|y~_q| / 64, -64 |E_q|, -1, -1 (h), -2^-12 (S_c), 0, 0 as
+        // stored: pass 1 computes G^ - bounds - h - S_c
         const float2 qq = p.qs[qpix];
-        sq[gq] = qq.x; hq[gq] = qq.y;
+        hq[gq] = qq.y;
+        qzero[gq] = qq.x == KM_Q_ZERO;
+        qbad |= qq.x == KM_Q_BAD;
     }
+    // a list with a row the screen does not cover (range, NaN) is handed to the exact search as a whole
+    const bool list_bad = __ballot(qbad) != 0ull || p.cell_bad[ccell] != 0;
 
     const int nchunks = (cnpts + KM_CHUNK - 1) / KM_CHUNK;
     const size_t cbase = km_cell_base(g, ci, cj);
@@ -382,6 +481,7 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     // issue order).  Chunks and tiles past the end of the cell are still staged/processed
     // (sentinel rows) so that these counts are exact.
     // (counted waits need immediates: one instantiation per count)
+    // (counted waits need immediates: one instantiation per count)
     auto wait_ring = [&](int pass) {
         if (pass == 0) {
             if (n_w == KM_MAXNW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KM_NBUF - 2) * KM_MAXNW) : "memory");
@@ -391,6 +491,14 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KM_NBUF - 2) * (KM_MAXNW - 1) + 2 * KM_SPC) : "memory");
         }
         __builtin_amdgcn_s_barrier();
+    };
+    // The pass-2 count above assumes that the stores of chunks c-1 and c really were issued: a wave that has not issued them
+    // (every wave in front of the first chunk; idle waves, which stage but skip the tiles, in every chunk) would pass the wait
+    // before the DMA of chunk c+1 has landed.  Such a wave issues the same number of stores with an offset beyond the
+    // buffer's range instead (dropped by the hardware, counted by vmcnt like the real ones).
+    auto dummy_stores = [&]() {
+#pragma unroll
+        for (int i = 0; i < KM_SPC; i++) __builtin_amdgcn_raw_buffer_store_b32(0u, evrsrc, (int)0xFFFFFF00u, 0, 0);
     };
     // Epilogues.  Pass 1: the maximum of the 16 values of this lane's tile column enters the lane's top-5.
     // Pass 2: 16-bit mask of the rows that qualify (bit r <-> accumulator register r) -> one event word.
@@ -477,20 +585,22 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
         // one, so the VALU work runs while the matrix pipe is busy.  The pipeline starts with a harmless unit (-inf).
         pend = minus_inf;
         pend_tile = 0;
+        if (pass == 1) dummy_stores();                      // stand in for the stores of a chunk in front of the first
         for (int chunk = 0; chunk < nchunks; chunk++) {
             const int buf = chunk % KM_NBUF;
             stage(chunk + KM_NBUF - 1, (chunk + KM_NBUF - 1) % KM_NBUF);                // that buffer was released by the previous barrier
             const char *ab = abuf + (size_t)buf * KM_ABUF;
             if (wave_active) { if (pass == 0) tiles(KmC<0>(), chunk, ab); else tiles(KmC<1>(), chunk, ab); }
+            else if (pass == 1) dummy_stores();
             wait_ring(pass);
         }
         if (wave_active) { if (pass == 0) epi1(pend, 1); else epi2(pend, 1, pend_tile); }   // drain the pipeline
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the over-staged chunks before the buffers are reused
         __builtin_amdgcn_s_barrier();
         if (pass == 0) {
-            // merge the two half-lanes of every query; pass-2 values v qualify iff v >= a5 - 2 S_q - s, where s covers the
-            // rounding of the canonical float32 distance (relative < 1.1e-5) and |y_q - y_c|^2 = |x_q - x_c|^2 (1 +- 2e-6): twice
-            // 1.35e-5 of 64^2 d^2 / 2 = 0.5|q|^2 - tau <= hq - (a5 - S_q)
+            // merge the two half-lanes of every query; pass-2 values v qualify iff v >= a5 - s, where s covers the rounding of
+            // the canonical float32 distance (relative < 1.1e-5) and |y_q - y_c|^2 = |x_q - x_c|^2 (1 +- 2e-6): twice
+            // 1.35e-5 of 64^2 d^2 / 2 = 0.5 |x_q|^2 - tau <= hq - a5
 #pragma unroll
             for (int gq = 0; gq < 2; gq++) {
                 float o[5];
@@ -499,18 +609,23 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
 #pragma unroll
                 for (int i = 0; i < 5; i++) top5_insert_desc(a5[gq], o[i]);
                 const float a5v = a5[gq][4];
-                const float x = a5v - 2.0f * sq[gq] - 2.7e-5f * (hq[gq] - a5v + sq[gq]);
-                const float th = fmaxf(x - fabsf(x) * 1e-6f - 1e-6f, -55000.0f);   // real values are > -50000, sentinel rows -60000
+                const float x = a5v - 2.7e-5f * fmaxf(hq[gq] - a5v, 0.0f);
+                // (the float32 roundings of x itself: a few ulp of its two terms)
+                float th = fmaxf(x - 1e-6f * (fabsf(a5v) + 2.7e-5f * hq[gq]), -55000.0f);   // real values are > -50000, sentinel rows -60000
+                // an all-zero query takes the cell's own list (knn_cell_post_kernel): no events
+                if (qzero[gq]) th = 60000.0f;
                 // Pass 2 subtracts the threshold inside the matrix core: two f16 pieces of th' (22 bits) times the 1.0 the
                 // candidate rows carry at k = 46, 47.  th' lies below th by the accumulation allowance eta = 7.7e-6 on the two extra
                 // products (|pieces| <= 1.001 |th'|) and by more than the pieces' truncation (2^-22 = 2.4e-7 relative, < 2^-24
                 // absolute in the subnormal range), so v >= th implies a computed v - th' >= 0; sentinel rows (-60000, no
-                // 1.0) stay negative.  The n slot and the S_c selector change sign: v = G^ + n_q n_c - h + S_c.
-                const float thp = th - 1e-5f * fabsf(th) - 1e-5f;
+                // 1.0) stay negative.  The bound slots and the S_c selector change sign: v = G^ + bounds - h + S_c.
+                const float thp = th - 1e-5f * fabsf(th) - 6e-8f;
                 if (half == 1) {
                     half8 b2 = bfrag[gq][KM_KSTEPS - 1];
                     b2[KM_SLOT_N - 40] = -b2[KM_SLOT_N - 40];
-                    b2[KM_SLOT_S - 40] = (_Float16)1.0f;
+                    b2[KM_SLOT_QE - 40] = -b2[KM_SLOT_QE - 40];
+                    b2[KM_SLOT_EN - 40] = -b2[KM_SLOT_EN - 40];
+                    b2[KM_SLOT_S - 40] = -b2[KM_SLOT_S - 40];
                     const _Float16 p1 = (_Float16)thp;
                     const _Float16 p2 = (_Float16)(thp - (float)p1);
                     b2[KM_SLOT_ONE - 40] = -p1; b2[KM_SLOT_ONE + 1 - 40] = -p2;
@@ -521,7 +636,7 @@ __global__ void __launch_bounds__(KM_THREADS, 4) knn_screen_kernel(KmGeom a, KmS
     }
     if (!wave_active) return;
 #pragma unroll
-    for (int gq = 0; gq < 2; gq++) p.ev_cnt[lid * 128 + gq * 64 + lane] = (uint8_t)(cnt[gq] >= evrows ? 255 : cnt[gq]);
+    for (int gq = 0; gq < 2; gq++) p.ev_cnt[lid * 128 + gq * 64 + lane] = (uint8_t)(list_bad || cnt[gq] >= evrows ? 255 : cnt[gq]);
 }
 
 // ------------------------------------------------------------------------------------------------ resolve
@@ -559,9 +674,11 @@ struct KmResolve {
     const void *d1, *d2;           // float32 (H,W,68) or binary16 (H,W,72)
     const uint32_t *ev;
     const uint8_t *ev_cnt;
+    const float2 *qs;              // (KM_Q_* flag, .) per image-1 pixel
+    const KmCellTop *ztop;         // per candidate cell: the answer for an all-zero query
     uint32_t *proposals;
     float *lcosts;
-    int *ovf_count;                // overflow list: entries (qcell, first query, ci, cj) for knn_fix_kernel
+    int *ovf_count;                // lists for knn_fix_kernel: entries (qcell, first query, ci, cj); one slot per list of the pass
     int4 *ovf_list;
     int ovf_cap;
 };
@@ -624,6 +741,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
     if (!qvalid) qi = qnpts - 1;
     const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
     const size_t qpix = (size_t)qy * g.W + qx;
+    const bool qzero = p.qs[qpix].x == KM_Q_ZERO;          // all-zero descriptor: no events, the cell's own list is the answer
     {
         rows.issue((rs_gptr)p.d1, (uint32_t)qpix * PIECES, true);
         float4 qv[17];
@@ -735,6 +853,11 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
         }
         done += nev;
         } while (__ballot(done < total));
+        if (qzero) {
+            const KmCellTop zt = p.ztop[cj * g.ncx + ci];
+#pragma unroll
+            for (int i = 0; i < 5; i++) { keys[i] = zt.idx[i]; costs[i] = zt.cost[i]; }
+        }
         // ---- emit (daisy i flann.py:174-180)
         if (qvalid) {
             const size_t pix = (size_t)qy * g.W + qx;
@@ -804,28 +927,66 @@ static size_t num_lists(const dflow_params *p)
     return (size_t)g.ncx * g.ncy * qwaves * win * win;
 }
 
-#define KM_OVF_CAP 8192
-
-static size_t knn_mfma_ws_bytes_for(const dflow_params *p, int evrows)
-{
-    size_t N = (size_t)p->pich * p->picw;
-    size_t nl = num_lists(p);
-    return (N + km_total_rows(make_geom(p))) * KM_K * sizeof(_Float16) + N * sizeof(float2) + 1024 +
-           DFLOW_DESC * DFLOW_DESC * sizeof(double) + knn_pca_ws_bytes() + 512 +
-           KM_OVF_CAP * sizeof(int4) + nl * (KM_LIST_WORDS(evrows) * sizeof(uint32_t) + 128) + 1024;
-}
-
-// entries per lane of the event lists: as many as fit below the scratch of the BCD stage (the workspace is one buffer for
-// all stages, so the lists then cost nothing), at least 16
+// entries per lane of the event lists: one per tile of the largest cell, + 1 (the last entry of a list is never valid), so
+// that no list can run out; cells beyond KM_EVROWS_MAX - 1 tiles: KM_EVROWS_MAX
 static int km_evrows(const dflow_params *p)
 {
-    const size_t budget = bcd_ws_bytes(p);
-    for (int e = KM_EVROWS_MAX; e > 16; e -= 8)
-        if (knn_mfma_ws_bytes_for(p, e) <= budget) return e;
-    return 16;
+    const int tiles = km_pad(max_cell_points(make_geom(p))) / 32;
+    return tiles + 1 < KM_EVROWS_MAX ? tiles + 1 : KM_EVROWS_MAX;
 }
 
-size_t knn_mfma_ws_bytes(const dflow_params *p) { return knn_mfma_ws_bytes_for(p, km_evrows(p)); }
+// the kNN stage's part of the workspace
+struct KmWs {
+    _Float16 *h1, *h2;          // prepared rows: image 1 in pixel order, image 2 cell by cell in tile position order
+    float2 *qs, *z0;            // per image-1 pixel (flag, 0.5 |x|^2); per image-2 position (|c|^2, |c|_1)
+    uint8_t *zflag;             // per image-2 position: all-zero row
+    int *ctr;                   // [0] lists handed to knn_fix_kernel, [1] flags (bit 0: the basis failed its check), then one
+    int *cell_bad;              //     flag per candidate cell; zeroed together at the start of a call
+    size_t zero_bytes;
+    float *vt;                  // principal axes, [component][dimension]
+    void *pca_ws;
+    KmCellTop *ztop;
+    int4 *ovf;                  // one slot per list
+    uint32_t *ev;
+    uint8_t *ev_cnt;
+    size_t nl, bytes;
+    int evrows;
+};
+
+static KmWs km_ws(const dflow_params *p, void *ws)
+{
+    const Geom g = make_geom(p);
+    const size_t N = (size_t)g.H * g.W, rows2 = km_total_rows(g), ncells = (size_t)g.ncx * g.ncy;
+    auto align256 = [](char *w) { return (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255); };
+    KmWs k;
+    char *w = (char *)ws;
+    k.nl = num_lists(p);
+    k.evrows = km_evrows(p);
+    k.h1 = (_Float16 *)w; w += N * KM_K * sizeof(_Float16);
+    k.h2 = (_Float16 *)w; w += rows2 * KM_K * sizeof(_Float16);
+    k.qs = (float2 *)w; w += N * sizeof(float2);
+    k.z0 = (float2 *)w; w += rows2 * sizeof(float2);
+    k.zflag = (uint8_t *)w; w += rows2;
+    w = align256(w);
+    k.ctr = (int *)w; w += 256;
+    k.cell_bad = (int *)w; w += ncells * sizeof(int);
+    k.zero_bytes = 256 + ncells * sizeof(int);
+    w = align256(w);
+    k.vt = (float *)w; w += DFLOW_DESC * DFLOW_DESC * sizeof(float);
+    w = align256(w);
+    k.pca_ws = w; w += knn_pca_ws_bytes();
+    w = align256(w);
+    k.ztop = (KmCellTop *)w; w += ncells * sizeof(KmCellTop);
+    w = align256(w);
+    k.ovf = (int4 *)w; w += k.nl * sizeof(int4);
+    w = align256(w);
+    k.ev = (uint32_t *)w; w += k.nl * KM_LIST_WORDS(k.evrows) * sizeof(uint32_t);
+    k.ev_cnt = (uint8_t *)w; w += k.nl * 128;
+    k.bytes = (size_t)(w - (char *)ws) + 256;
+    return k;
+}
+
+size_t knn_mfma_ws_bytes(const dflow_params *p) { return km_ws(p, nullptr).bytes; }
 
 bool knn_mfma_supported(const dflow_params *p)
 {
@@ -842,70 +1003,124 @@ int launch_knn_mfma(const dflow_params *p, const void *d1, const void *d2, uint3
 {
     auto mark = [&](int k) { if (tev) (void)hipEventRecord(tev[k], s); };
     Geom g = make_geom(p);
-    size_t N = (size_t)g.H * g.W, nl = num_lists(p);
-    auto align256 = [](char *w) { return (char *)(((uintptr_t)w + 255) & ~(uintptr_t)255); };
-    char *w = (char *)ws;
-    _Float16 *h1 = (_Float16 *)w; w += N * KM_K * sizeof(_Float16);
-    _Float16 *h2 = (_Float16 *)w; w += km_total_rows(g) * KM_K * sizeof(_Float16);   // position order, padded cells
-    float2 *qs = (float2 *)w; w += N * sizeof(float2);
-    w = align256(w);
-    int *ctr = (int *)w; w += 256;              // ctr[0] = overflow count, ctr[1] = flags
-    float *mu = (float *)w; w += 512;           // centre of the screen's coordinates
-    float *vt = (float *)w; w += DFLOW_DESC * DFLOW_DESC * sizeof(double);     // principal axes, [component][dimension]
-    w = align256(w);
-    void *pca_ws = w; w += knn_pca_ws_bytes();
-    int4 *ovf = (int4 *)w; w += KM_OVF_CAP * sizeof(int4);
-    w = align256(w);
-    const int evrows = km_evrows(p);
-    uint32_t *ev = (uint32_t *)w; w += nl * KM_LIST_WORDS(evrows) * sizeof(uint32_t);
-    uint8_t *ev_cnt = (uint8_t *)w;
-    if (hipMemsetAsync(ctr, 0, 256, s) != hipSuccess)
+    const size_t N = (size_t)g.H * g.W;
+    const KmWs k = km_ws(p, ws);
+    if (hipMemsetAsync(k.ctr, 0, k.zero_bytes, s) != hipSuccess)
         return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed in launch_knn_mfma");
     int nb = (int)((N + 255) / 256);
     mark(0);
     const bool f16 = descr_f16(p);
-    if (f16) hipLaunchKernelGGL(knn_mean_kernel<_Float16>, dim3(1), dim3(1024), 0, s, (const _Float16 *)d2, mu, (int)N);
-    else hipLaunchKernelGGL(knn_mean_kernel<float>, dim3(1), dim3(1024), 0, s, (const float *)d2, mu, (int)N);
-    int rc = launch_knn_pca(d2, f16, mu, vt, ctr + 1, pca_ws, (int)N, s);
+    int rc = launch_knn_pca(d2, f16, k.vt, k.ctr + 1, k.pca_ws, (int)N, s);
     if (rc) return rc;
     mark(1);
     const dim3 cgrid((km_pad(max_cell_points(g)) + 255) / 256, g.ncx * g.ncy);
     if (f16) {
-        hipLaunchKernelGGL(knn_prep_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16 *)d1, (const float *)mu, (const float *)vt, h1, qs, ctr + 1, g, 0);
-        hipLaunchKernelGGL(knn_prep_kernel<_Float16>, cgrid, dim3(256), 0, s, (const _Float16 *)d2, (const float *)mu, (const float *)vt, h2, (float2 *)nullptr, ctr + 1, g, 1);
+        hipLaunchKernelGGL(knn_prep_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16 *)d1, (const float *)k.vt, k.h1, k.qs, (float2 *)nullptr, (uint8_t *)nullptr, (int *)nullptr, g, 0);
+        hipLaunchKernelGGL(knn_prep_kernel<_Float16>, cgrid, dim3(256), 0, s, (const _Float16 *)d2, (const float *)k.vt, k.h2, (float2 *)nullptr, k.z0, k.zflag, k.cell_bad, g, 1);
     } else {
-        hipLaunchKernelGGL(knn_prep_kernel<float>, dim3(nb), dim3(256), 0, s, (const float *)d1, (const float *)mu, (const float *)vt, h1, qs, ctr + 1, g, 0);
-        hipLaunchKernelGGL(knn_prep_kernel<float>, cgrid, dim3(256), 0, s, (const float *)d2, (const float *)mu, (const float *)vt, h2, (float2 *)nullptr, ctr + 1, g, 1);
+        hipLaunchKernelGGL(knn_prep_kernel<float>, dim3(nb), dim3(256), 0, s, (const float *)d1, (const float *)k.vt, k.h1, k.qs, (float2 *)nullptr, (uint8_t *)nullptr, (int *)nullptr, g, 0);
+        hipLaunchKernelGGL(knn_prep_kernel<float>, cgrid, dim3(256), 0, s, (const float *)d2, (const float *)k.vt, k.h2, (float2 *)nullptr, k.z0, k.zflag, k.cell_bad, g, 1);
     }
+    hipLaunchKernelGGL(knn_cell_post_kernel, dim3(g.ncx * g.ncy), dim3(256), 0, s, k.h2, (const float2 *)k.z0, (const uint8_t *)k.zflag, k.ztop, g);
+    rc = dflow_check_launch("knn_cell_post_kernel");
+    if (rc) return rc;
 
     mark(2);
     KmGeom a;
     a.g = g; a.LP = p->label_pitch; a.tphi = p->tphi;
     a.qwaves = (max_cell_points(g) + KM_QPW - 1) / KM_QPW;
-    a.evrows = evrows;
+    a.evrows = k.evrows;
     int win = 2 * g.win + 1;
     int wgs_per_cell = (win * win * a.qwaves + KM_WAVES - 1) / KM_WAVES;
     KmScreen sc;
-    sc.h1 = h1; sc.h2 = h2; sc.qs = qs; sc.ev = ev; sc.ev_cnt = ev_cnt;
+    sc.h1 = k.h1; sc.h2 = k.h2; sc.qs = k.qs; sc.cell_bad = k.cell_bad; sc.ev = k.ev; sc.ev_cnt = k.ev_cnt;
     size_t shmem = (size_t)KM_NBUF * KM_ABUF;
     hipLaunchKernelGGL(knn_screen_kernel, dim3(g.ncx * g.ncy * wgs_per_cell), dim3(KM_THREADS), shmem, s, a, sc);
     rc = dflow_check_launch("knn_screen_kernel");
     if (rc) return rc;
     mark(3);
     KmResolve rs;
-    rs.d1 = d1; rs.d2 = d2; rs.ev = ev; rs.ev_cnt = ev_cnt; rs.proposals = proposals; rs.lcosts = lcosts;
-    rs.ovf_count = ctr; rs.ovf_list = ovf; rs.ovf_cap = KM_OVF_CAP;
+    rs.d1 = d1; rs.d2 = d2; rs.ev = k.ev; rs.ev_cnt = k.ev_cnt; rs.qs = k.qs; rs.ztop = k.ztop; rs.proposals = proposals; rs.lcosts = lcosts;
+    rs.ovf_count = k.ctr; rs.ovf_list = k.ovf; rs.ovf_cap = (int)k.nl;
     if (f16) hipLaunchKernelGGL(knn_resolve_kernel<true>, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
     else hipLaunchKernelGGL(knn_resolve_kernel<false>, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
     rc = dflow_check_launch("knn_resolve_kernel");
     if (rc) return rc;
     mark(4);
-    rc = launch_knn_fix(p, d1, d2, proposals, lcosts, ctr, ovf, KM_OVF_CAP, ctr + 1, s);
+    rc = launch_knn_fix(p, d1, d2, proposals, lcosts, k.ctr, k.ovf, (int)k.nl, k.ctr + 1, s);
     if (rc) return rc;
     mark(5);
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((unsigned)((N * 16 + 255) / 256)), dim3(256), 0, s, g, a.LP, proposals, lcosts, nprop, bestlabels);
     mark(6);
     return dflow_check_launch("knn_finalize_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------ statistics (measurement aid)
+// What the screen left in the workspace: one block per event list (threads = 2 groups x 64 lanes), then one pass over the
+// image-1 records and the image-2 positions.
+__global__ void __launch_bounds__(128) knn_stats_lists_kernel(const uint32_t *__restrict__ ev, const uint8_t *__restrict__ ev_cnt, int evrows,
+                                                              unsigned long long *__restrict__ out)
+{
+    const size_t lid = blockIdx.x;
+    const int gq = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cnt = ev_cnt[lid * 128 + threadIdx.x];
+    unsigned long long entries = 0, events = 0;
+    if (cnt != 255) {
+        entries = (unsigned long long)cnt;
+        const uint32_t *e = ev + lid * KM_LIST_WORDS(evrows) + (size_t)gq * evrows * 64 + lane;
+        for (int i = 0; i < cnt; i++) events += (unsigned long long)__popc(e[i * 64] & 0xFFFFu);
+    }
+    unsigned long long mx = entries;
+    for (int off = 32; off > 0; off >>= 1) { entries += __shfl_xor(entries, off); events += __shfl_xor(events, off); const unsigned long long o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+    if (lane == 0) { atomicAdd(out + 0, entries); atomicAdd(out + 1, events); atomicMax(out + 2, mx); }
+}
+
+__global__ void __launch_bounds__(256) knn_stats_rows_kernel(const float2 *__restrict__ qs, int npix, const uint8_t *__restrict__ zflag,
+                                                             const _Float16 *__restrict__ h2, size_t rows2, unsigned long long *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool zq = i < (size_t)npix && qs[i].x == KM_Q_ZERO, bq = i < (size_t)npix && qs[i].x == KM_Q_BAD;
+    const bool zc = i < rows2 && zflag[i] != 0;
+    const bool removed = zc && h2[i * KM_K + KM_SLOT_H] == (_Float16)60000.0f;
+    const unsigned long long b0 = __ballot(zq), b1 = __ballot(bq), b2 = __ballot(zc), b3 = __ballot(removed);
+    if ((threadIdx.x & 63) == 0) {
+        if (b0) atomicAdd(out + 3, (unsigned long long)__popcll(b0));
+        if (b1) atomicAdd(out + 4, (unsigned long long)__popcll(b1));
+        if (b2) atomicAdd(out + 5, (unsigned long long)__popcll(b2));
+        if (b3) atomicAdd(out + 6, (unsigned long long)__popcll(b3));
+    }
+}
+
+// h_out[KNN_STATS_N] (host), after a dflow_knn_proposals call on the same workspace: see include/dflow.h
+int knn_mfma_stats(const dflow_params *p, void *ws, hipStream_t s, int64_t *h_out)
+{
+    const KmWs k = km_ws(p, ws);
+    const Geom g = make_geom(p);
+    const size_t N = (size_t)g.H * g.W, rows2 = km_total_rows(g);
+    unsigned long long *dev = (unsigned long long *)(k.ctr + 16);            // 8 counters inside the zeroed control block
+    if (hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), s) != hipSuccess) return dflow_set_error(DFLOW_EHIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(knn_stats_lists_kernel, dim3((unsigned)k.nl), dim3(128), 0, s, (const uint32_t *)k.ev, (const uint8_t *)k.ev_cnt, k.evrows, dev);
+    const size_t m = N > rows2 ? N : rows2;
+    hipLaunchKernelGGL(knn_stats_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const float2 *)k.qs, (int)N, (const uint8_t *)k.zflag,
+                       (const _Float16 *)k.h2, rows2, dev);
+    int rc = dflow_check_launch("knn_stats kernels");
+    if (rc) return rc;
+    unsigned long long c[8];
+    int ctr[2];
+    if (hipMemcpyAsync(c, dev, sizeof(c), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(ctr, k.ctr, sizeof(ctr), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return dflow_set_error(DFLOW_EHIP, "knn_mfma_stats: copy back failed");
+    // (query, cell) pairs of the pass
+    long long pairs = 0;
+    for (int qcj = 0; qcj < g.ncy; qcj++)
+        for (int qci = 0; qci < g.ncx; qci++) {
+            const long long qn = (long long)(g.x1(qci) - g.x0(qci)) * (g.y1(qcj) - g.y0(qcj));
+            const int nx = min(g.ncx - 1, qci + g.win) - max(0, qci - g.win) + 1, ny = min(g.ncy - 1, qcj + g.win) - max(0, qcj - g.win) + 1;
+            pairs += qn * nx * ny;
+        }
+    h_out[0] = ctr[0]; h_out[1] = ctr[1]; h_out[2] = (int64_t)k.nl; h_out[3] = (int64_t)c[0]; h_out[4] = (int64_t)c[1]; h_out[5] = (int64_t)c[2];
+    h_out[6] = (int64_t)c[3]; h_out[7] = (int64_t)c[4]; h_out[8] = (int64_t)c[5]; h_out[9] = (int64_t)c[6]; h_out[10] = pairs; h_out[11] = k.evrows;
+    return DFLOW_OK;
 }
 
 // MFMA instructions the screen issues for these parameters (2 passes x KM_KSTEPS per 32 x 32 tile of padded cells), for

@@ -8,6 +8,6 @@
 
 // scratch of the two kernels (partial scatter matrices)
 size_t knn_pca_ws_bytes(void);
-// d2: (npix, 68) float32 or (f16) (npix, 72) binary16 descriptors, mu: their centre (68 float32) -> vt: [68 components][68
-// dimensions] float32, rows sorted by decreasing eigenvalue; sets bit 0 of *flags if |V^T V - I|_F > PCA_DELTA_MAX (NaN input)
-int launch_knn_pca(const void *d2, bool f16, const float *mu, float *vt, int *flags, void *ws, int npix, hipStream_t s);
+// d2: (npix, 68) float32 or (f16) (npix, 72) binary16 descriptors -> vt: [68 components][68 dimensions] float32, the principal
+// axes of their second-moment matrix, rows sorted by decreasing eigenvalue; sets bit 0 of *flags if |V^T V - I|_F > PCA_DELTA_MAX
+int launch_knn_pca(const void *d2, bool f16, float *vt, int *flags, void *ws, int npix, hipStream_t s);

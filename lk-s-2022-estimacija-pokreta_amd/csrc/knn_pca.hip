@@ -6,7 +6,7 @@
 // leading KM_KD directions only and bounds the rest by Cauchy-Schwarz (one extra K slot, |q_D| |c_D|), which cuts
 // the MFMAs per tile from 5 to 3.  ANY orthonormal basis gives exact results; a good one keeps the bound tight.
 //
-//   knn_cov_kernel     partial scatter matrices of PCA_SAMPLES evenly spaced pixels about the centre mu, one block per
+//   knn_cov_kernel     partial second-moment matrices (about the origin, see knn_mfma.hip) of PCA_SAMPLES evenly spaced pixels, one block per
 //                      PCA_BLOCK_SAMPLES samples, float64, fixed summation order (deterministic basis)
 //   knn_jacobi_kernel  one workgroup: sum of the partials, cyclic Jacobi eigenvalue iteration in float32, Newton-Schulz
 //                      polish of V in float64, columns sorted by decreasing eigenvalue, rounded to float32 and written as
@@ -25,14 +25,14 @@
 #endif
 
 template <typename T>
-__global__ void __launch_bounds__(256) knn_cov_kernel(const T *__restrict__ d, const float *__restrict__ mu,
-                                                      double *__restrict__ partial, int npix)
+__global__ void __launch_bounds__(256) knn_cov_kernel(const T *__restrict__ d, double *__restrict__ partial, int npix)
 {
     __shared__ float xs[PCA_BLOCK_SAMPLES][PCA_LD];
     const int nsamp = npix < PCA_SAMPLES ? npix : PCA_SAMPLES, stride = npix / nsamp;
     for (int e = threadIdx.x; e < PCA_BLOCK_SAMPLES * PCA_N; e += 256) {
         const int sl = e / PCA_N, k = e % PCA_N, sidx = blockIdx.x * PCA_BLOCK_SAMPLES + sl;
-        xs[sl][k] = sidx < nsamp ? (float)d[(size_t)sidx * stride * DescPitch<T>::value + k] - mu[k] : 0.0f;
+        const float v = sidx < nsamp ? (float)d[(size_t)sidx * stride * DescPitch<T>::value + k] : 0.0f;
+        xs[sl][k] = fabsf(v) < 1e4f ? v : 0.0f;               // NaN / inf / absurd values do not steer the basis (any basis is valid)
     }
     __syncthreads();
     for (int e = threadIdx.x; e < PCA_N * PCA_N; e += 256) {
@@ -220,11 +220,11 @@ __global__ void __launch_bounds__(1024) knn_jacobi_kernel(const double *__restri
 
 size_t knn_pca_ws_bytes(void) { return (size_t)PCA_BLOCKS * PCA_N * PCA_N * sizeof(double); }
 
-int launch_knn_pca(const void *d2, bool f16, const float *mu, float *vt, int *flags, void *ws, int npix, hipStream_t s)
+int launch_knn_pca(const void *d2, bool f16, float *vt, int *flags, void *ws, int npix, hipStream_t s)
 {
     double *partial = (double *)ws;
-    if (f16) hipLaunchKernelGGL(knn_cov_kernel<_Float16>, dim3(PCA_BLOCKS), dim3(256), 0, s, (const _Float16 *)d2, mu, partial, npix);
-    else hipLaunchKernelGGL(knn_cov_kernel<float>, dim3(PCA_BLOCKS), dim3(256), 0, s, (const float *)d2, mu, partial, npix);
+    if (f16) hipLaunchKernelGGL(knn_cov_kernel<_Float16>, dim3(PCA_BLOCKS), dim3(256), 0, s, (const _Float16 *)d2, partial, npix);
+    else hipLaunchKernelGGL(knn_cov_kernel<float>, dim3(PCA_BLOCKS), dim3(256), 0, s, (const float *)d2, partial, npix);
     hipLaunchKernelGGL(knn_jacobi_kernel, dim3(1), dim3(1024), 0, s, (const double *)partial, vt, flags);
     return dflow_check_launch("knn_jacobi_kernel");
 }

@@ -37,6 +37,7 @@ class DiscreteFlow:
         self.p = _lib.default_params(pich, picw, cellh, cellw, seed=seed, **overrides)
         _lib.check(0 if _lib.lib().dflow_workspace_bytes(C.byref(self.p)) else -1, "dflow_workspace_bytes")
         self.device = torch.device(device)
+        self._descr_f16 = bool(self.p.flags & _lib.FLAG_DESCR_F16)     # storage mode of the descriptor planes: fixed here
         H, W, LP = pich, picw, self.p.label_pitch
         dev = self.device
         # float32 (H,W,68), or with DFLOW_FLAG_DESCR_F16 binary16 (H,W,72): 68 values + 4 zero pads per pixel (include/dflow.h)
@@ -55,7 +56,7 @@ class DiscreteFlow:
     # ------------------------------------------------------------------ helpers
     @property
     def descr_f16(self):
-        return bool(self.p.flags & _lib.FLAG_DESCR_F16)
+        return self._descr_f16
 
     def _new_descr(self):
         H, W = self.p.pich, self.p.picw
@@ -67,6 +68,11 @@ class DiscreteFlow:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _pp(self):
+        # the planes were allocated for one storage mode; a flag flipped afterwards would make the kernels read or write
+        # 272-byte rows in 144-byte rows (or the reverse)
+        if bool(self.p.flags & _lib.FLAG_DESCR_F16) != self._descr_f16:
+            raise _lib.DflowError("DFLOW_FLAG_DESCR_F16 changed after construction: the descriptor planes are %s"
+                                  % ("binary16 (H,W,72)" if self._descr_f16 else "float32 (H,W,68)"))
         return C.byref(self.p)
 
     # ------------------------------------------------------------------ reference-named stages
@@ -126,6 +132,17 @@ class DiscreteFlow:
                                                         self.ws.data_ptr(), self.ws_bytes, self._stream(), ms, C.byref(issued)),
                    "dflow_knn_proposals_timed")
         return dict(zip(self.KNN_KERNELS, (float(v) for v in ms))), float(issued.value)
+
+    KNN_STATS = ("lists_exact", "flags", "lists", "entries", "events", "max_entries_per_lane", "zero_queries", "bad_queries",
+                 "zero_candidates", "zero_candidates_removed", "query_cell_pairs", "list_capacity")
+
+    def knn_stats(self):
+        """dflow_knn_screen_stats: what the MFMA screen of the last generisi() did (call before the next stage reuses the workspace)."""
+        out = (C.c_int64 * len(self.KNN_STATS))()
+        _lib.check(_lib.lib().dflow_knn_screen_stats(self._pp(), self.ws.data_ptr(), self.ws_bytes, self._stream(), out), "dflow_knn_screen_stats")
+        st = dict(zip(self.KNN_STATS, (int(v) for v in out)))
+        st["events_per_query_cell"] = round(st["events"] / max(1, st["query_cell_pairs"]), 3)
+        return st
 
     def nasumicni(self):
         """daisy i flann.py:205-233."""
@@ -199,6 +216,12 @@ class DiscreteFlow:
                            | (proposals[..., 1].astype(np.int16).view(np.uint16).astype(np.uint32) << 16))
         lc = np.full((H, W, LP), 1000.0, np.float32)
         lc[..., :L] = lcosts.astype(np.float32)
+        # the device keeps the data costs as float32: exact for everything the reference writes (min(tphi, a float32 sum),
+        # daisy i flann.py:179-180,228-229) -- anything else would silently change the DP, so it is refused
+        if not np.array_equal(lc[..., :L].astype(np.float64), lcosts):
+            raise ValueError("lcosts holds values that are not float32-exact (the reference's files are): refusing to round them")
+        if proposals.min() < -32768 or proposals.max() > 32767:
+            raise ValueError("proposals outside the int16 range of the packed device layout")
         self.proposals.copy_(torch.from_numpy(packed.view(np.int32)))
         self.lcosts.copy_(torch.from_numpy(lc))
         self.nprop.copy_(torch.from_numpy(nprop.astype(np.int32)))

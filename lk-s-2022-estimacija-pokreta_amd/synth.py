@@ -64,20 +64,70 @@ def forward_gt(H, W, seed, amp_x=40.0, amp_y=20.0, iters=60):
     return np.stack([fy, fx], axis=-1)
 
 
-def make_pair(H, W, seed=0, amp_x=40.0, amp_y=20.0, noise=2.0):
-    """Returns (img1, img2, gt) with img uint8 (H,W,3) BGR and gt (H,W,2) float64 [dy,dx] = forward_gt: the true flow of
-    image 1's pixels (where the warp leaves the image the field is still defined; the clipped source has no match there)."""
-    rng = np.random.default_rng(seed)
-    chans = [_smooth_noise(rng, H, W) for _ in range(3)]
-    img1 = np.stack(chans, axis=-1) * 255.0
-    gt = gt_flow(H, W, seed, amp_x, amp_y)
+def _warp(img, gt):
+    """Bilinear backward warp: out(q) = img(q - gt(q)), source clamped to the image."""
+    H, W = gt.shape[:2]
     yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
     sy = np.clip(yy - gt[..., 0], 0, H - 1.001); sx = np.clip(xx - gt[..., 1], 0, W - 1.001)
     y0 = np.floor(sy).astype(int); x0 = np.floor(sx).astype(int)
     fy = (sy - y0)[..., None]; fx = (sx - x0)[..., None]
-    img2 = ((1 - fy) * ((1 - fx) * img1[y0, x0] + fx * img1[y0, x0 + 1])
-            + fy * ((1 - fx) * img1[y0 + 1, x0] + fx * img1[y0 + 1, x0 + 1]))
-    img2 = img2 + rng.normal(0.0, noise, img2.shape)
+    return ((1 - fy) * ((1 - fx) * img[y0, x0] + fx * img[y0, x0 + 1])
+            + fy * ((1 - fx) * img[y0 + 1, x0] + fx * img[y0 + 1, x0 + 1]))
+
+
+def _box_blur(a, r, times=3):
+    """`times` box filters of radius r along both axes (close to a Gaussian of sigma r * sqrt(times / 3)), edges replicated."""
+    for _ in range(times):
+        for ax in (0, 1):
+            pad = [(0, 0)] * a.ndim
+            pad[ax] = (r + 1, r)
+            c = np.cumsum(np.pad(a, pad, mode="edge"), axis=ax)
+            n = a.shape[ax]
+            hi = np.take(c, np.arange(2 * r + 1, 2 * r + 1 + n), axis=ax)
+            lo = np.take(c, np.arange(0, n), axis=ax)
+            a = (hi - lo) / (2 * r + 1)
+    return a
+
+
+STYLES = ("dense", "low_texture")
+
+
+def low_texture_regions(H, W, seed=0):
+    """Region map of the "low_texture" style, (H,W) uint8: 0 dense texture, 1 saturated sky (exactly 255: exactly-zero DAISY
+    descriptors, daisy i flann.py:66 uses NRM_NONE), 2 low-contrast road (a texture of +-2 grey levels, noise below one
+    grey level), 3 blurred, 4 a pattern that repeats every 16 px.  What a KITTI frame has and smoothed noise has not."""
+    yy, xx = np.meshgrid(np.arange(H) / H, np.arange(W) / W, indexing="ij")
+    ph = 2 * np.pi * ((seed % 97) / 97.0)
+    reg = np.zeros((H, W), np.uint8)
+    reg[yy < 0.30 + 0.05 * np.sin(2 * np.pi * 1.5 * xx + ph)] = 1                 # sky: about 30 % of the frame
+    reg[(yy > 0.62 + 0.03 * np.cos(2 * np.pi * xx + ph)) & (yy < 0.86)] = 2       # road band: about 24 %
+    reg[(yy > 0.36) & (yy < 0.58) & (xx > 0.06) & (xx < 0.30)] = 3                 # blurred box
+    reg[(yy > 0.36) & (yy < 0.58) & (xx > 0.64) & (xx < 0.90)] = 4                 # repeated pattern
+    return reg
+
+
+def make_pair(H, W, seed=0, amp_x=40.0, amp_y=20.0, noise=2.0, style="dense"):
+    """Returns (img1, img2, gt) with img uint8 (H,W,3) BGR and gt (H,W,2) float64 [dy,dx] = forward_gt: the true flow of
+    image 1's pixels (where the warp leaves the image the field is still defined; the clipped source has no match there).
+    style "dense": texture everywhere (the best case for the kNN screen); "low_texture": low_texture_regions() on top."""
+    if style not in STYLES:
+        raise ValueError("style must be one of %s" % (STYLES,))
+    rng = np.random.default_rng(seed)
+    chans = [_smooth_noise(rng, H, W) for _ in range(3)]
+    img1 = np.stack(chans, axis=-1) * 255.0
+    gt = gt_flow(H, W, seed, amp_x, amp_y)
+    sig = np.full((H, W, 1), float(noise))
+    if style == "low_texture":
+        reg = low_texture_regions(H, W, seed)[..., None]
+        blurred = _box_blur(img1, 6)
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        pattern = (128.0 + 60.0 * np.sin(2 * np.pi * xx / 16.0) * np.cos(2 * np.pi * yy / 16.0))[..., None] * np.ones(3)
+        img1 = np.where(reg == 1, 400.0, img1)                                 # far beyond 255: saturated after the warp and the noise too
+        img1 = np.where(reg == 2, 90.0 + (img1 - 127.5) * (2.0 / 127.5), img1)
+        img1 = np.where(reg == 3, blurred, img1)
+        img1 = np.where(reg == 4, pattern, img1)
+        sig = np.where(reg == 2, 0.4, sig)
+    img2 = _warp(img1, gt) + rng.normal(0.0, 1.0, img1.shape) * _warp(sig, gt)
     to_u8 = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
     return to_u8(img1), to_u8(img2), forward_gt(H, W, seed, amp_x, amp_y)
 

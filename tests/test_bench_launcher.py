@@ -27,6 +27,18 @@ def test_bench_self_launches_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["unit"] == "Mpix/s" and d["value"] > 0 and d["data"] == "stub"
     assert abs(d["value"] - 2 * 3 * 436 * 1024 / (d["ms_per_step"] * 3e-3) / 1e6) < 1e-6 * d["value"]
+    # the fixed batch (BASELINE configs[3]): 16 passes whatever the number of ranks, pass p -> rank p mod 2: strong scaling
+    fb = d["fixed_batch"]
+    assert fb["passes"] == 16 and fb["passes_per_rank"] == 8 and fb["n_gpus"] == 2 and fb["scaling"] == "strong"
+    assert abs(fb["Mpix/s"] - 16 * 436 * 1024 / (fb["ms"] * 1e-3) / 1e6) < 1e-6 * fb["Mpix/s"]
+
+
+def test_fixed_batch_with_a_ragged_share():
+    # 5 passes over 2 ranks: rank 0 has 3, rank 1 has 2 and must still take part in the third gather
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--stub", "--fixed-batch", "5"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    assert d["fixed_batch"]["passes"] == 5 and d["fixed_batch"]["passes_per_rank"] == 3
 
 
 def test_bench_rank_failure_is_reported():

@@ -1,8 +1,8 @@
-"""ms per (pair, sweep) of the batched BCD sweeps for 1..8 passes per launch: python scratch/chain_batch_sizes.py [variant.so]"""
+"""Batched BCD sweeps (8 passes per launch) and one pass alone: python tools/chain_time.py [variant.so]"""
 import sys, os, importlib, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 _lib = importlib.import_module("lk-s-2022-estimacija-pokreta_amd._lib")
-if len(sys.argv) > 1: _lib.LIB_PATH = os.path.join(ROOT, "scratch", "prof_build", sys.argv[1])
+if len(sys.argv) > 1: _lib.LIB_PATH = os.path.join(ROOT, "tools", "prof_build", sys.argv[1])
 synth = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.synth")
 pl = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.pipeline")
 H, W = 436, 1024
@@ -19,8 +19,6 @@ def ev_time(fn, n=3):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return min(ts)
-out = []
-for b in range(1, 9):
-    t = ev_time(lambda: pl.ceoBCD_batch(dfs[:b], 2)) / (2 * b)
-    out.append("%d: %.3f" % (b, t))
-print(sys.argv[1:], "bcd ms per (pair, sweep) by passes per launch:", "  ".join(out))
+t8 = ev_time(lambda: pl.ceoBCD_batch(dfs, 2)) / 16
+t1 = ev_time(lambda: dfs[0].ceoBCD(2)) / 2
+print(sys.argv[1:], "bcd ms per (pair, sweep): batched x8 %.3f, alone %.3f" % (t8, t1), "labels", int(dfs[0].bestlabels.sum().item()))

@@ -1,9 +1,9 @@
-"""MFMA-screened kNN of a variant library against its brute-force kernel, every pixel: python scratch/knn_check.py [variant.so] [H W cellh cellw]"""
+"""MFMA-screened kNN of a variant library against its brute-force kernel, every pixel: python tools/knn_check.py [variant.so] [H W cellh cellw]"""
 import sys, os, importlib, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 _lib = importlib.import_module("lk-s-2022-estimacija-pokreta_amd._lib")
 args = sys.argv[1:]
-if args and args[0].endswith(".so"): _lib.LIB_PATH = os.path.join(ROOT, "scratch", "prof_build", args.pop(0))
+if args and args[0].endswith(".so"): _lib.LIB_PATH = os.path.join(ROOT, "tools", "prof_build", args.pop(0))
 synth = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.synth")
 pl = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.pipeline")
 geoms = [(436, 1024, 27, 64), (375, 1242, 25, 54), (97, 131, 9, 13)] if not args else [tuple(int(v) for v in args[:4])]

@@ -1,7 +1,7 @@
 import sys, os, importlib, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 _lib = importlib.import_module("lk-s-2022-estimacija-pokreta_amd._lib")
-if len(sys.argv) > 1: _lib.LIB_PATH = os.path.join(ROOT, "scratch", "prof_build", sys.argv[1])
+if len(sys.argv) > 1: _lib.LIB_PATH = os.path.join(ROOT, "tools", "prof_build", sys.argv[1])
 synth = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.synth")
 pl = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.pipeline")
 H, W = 436, 1024

@@ -1,8 +1,10 @@
 """profiles/pmc_knn.json from one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE ...) of
-scratch/knn_time.py: the clock the chip held during knn_screen_kernel (GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, MI355X_MICROARCH.md
+tools/knn_time.py: the clock the chip held during knn_screen_kernel (GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, MI355X_MICROARCH.md
 'DVFS give-back') and how busy its matrix pipes were.   usage: pmc_knn_json.py <pmc dir> <out.json>"""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 d, out = sys.argv[1], sys.argv[2]
 dur = defaultdict(list)
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
@@ -16,7 +18,8 @@ k = "knn_screen_kernel"
 c = {n: s / m for n, (m, s) in acc[k].items()}
 ns = sum(dur[k]) / len(dur[k])
 cyc = c["GRBM_GUI_ACTIVE"] / 8
-res = {"source": "rocprofv3 --kernel-trace --pmc " + " ".join(sorted(c)) + " -- python3 scratch/knn_time.py (one pair alone on the GPU)",
+res = {"source": "rocprofv3 --kernel-trace --pmc " + " ".join(sorted(c)) + " -- python3 tools/knn_time.py (one pair alone on the GPU)",
+       "csrc_sha16": bench.csrc_digest(),
        "knn_screen_kernel_launch_us_under_pmc": ns / 1e3,
        "knn_screen_kernel_effective_clock_ghz": cyc / ns,
        "knn_screen_kernel_mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc,
