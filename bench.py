@@ -285,7 +285,7 @@ def total_traffic_per_pass():
 
 def pmc_traffic(kernel, unit_grids=None, passes=1.0):
     """HBM bytes per launch of `kernel` from the tracked rocprofv3 --pmc summary (profiles/pmc_traffic.json, written by
-    scratch/pmc_to_json.py from separate FETCH_SIZE and WRITE_SIZE passes of the bench command; FETCH_SIZE already doubled as
+    tools/pmc_to_json.py from separate FETCH_SIZE and WRITE_SIZE passes of the bench command; FETCH_SIZE already doubled as
     MI355X_MICROARCH.md prescribes for gfx950's wide reads).  `unit_grids` = launch sizes in threads of ONE pass (column and
     row phases); a batched launch carries `passes` of them and moves that many times the bytes (every pass streams its own
     planes), so the per-pass traffic of every profiled multiple of a unit grid is averaged and scaled.  None if the file has

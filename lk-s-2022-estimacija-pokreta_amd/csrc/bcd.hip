@@ -37,7 +37,7 @@
 #define BCD_TB_STEPS 32                  // traceback chunk (steps) staged in LDS
 #define BCD_GROUPS 3                     // 64-label waves per pixel
 // Reserved second / third blocks per 64-label wave.  21 % / 2.6 % of the labels own one (mean 13 / 1.6 per wave of kNN
-// labels, scratch/list_stats.py: more than 40 / 24 on 0.1 % of the waves; the third wave holds the 22 neighbour labels: never
+// labels, scratch/list_stats.py (round 3, git history): more than 40 / 24 on 0.1 % of the waves; the third wave holds the 22 neighbour labels: never
 // more than 16 / 8); a label whose block does not fit (and every label with more than 15 members) is marked "more" and
 // continues in its 160-bit row.  Those rows are bump-allocated from a pool (BCD_POOL_DIV-th of the worst case); a row that
 // does not fit the pool is not stored and the chain kernel tests that label's remaining predecessors one by one.

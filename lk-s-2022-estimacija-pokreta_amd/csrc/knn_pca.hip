@@ -2,7 +2,7 @@
 //
 // Squared L2 distances do not change under an orthogonal change of basis, and DAISY descriptors are strongly
 // correlated (overlapping Gaussian histograms): in the principal basis of a frame's descriptors the trailing 26 of
-// the 68 directions carry < 0.1 % of the energy (scratch/pca_stats.py).  The screen runs its matrix products over the
+// the 68 directions carry < 0.1 % of the energy (scratch/pca_stats.py (round 3, git history)).  The screen runs its matrix products over the
 // leading KM_KD directions only and bounds the rest by Cauchy-Schwarz (one extra K slot, |q_D| |c_D|), which cuts
 // the MFMAs per tile from 5 to 3.  ANY orthonormal basis gives exact results; a good one keeps the bound tight.
 //

@@ -662,7 +662,7 @@ def _random_geometries(n, seed):
 @pytest.mark.parametrize("geom", _random_geometries(10, 7))
 def test_random_geometries_match_oracle(torch_, oracle, synth, geom):
     """Randomly drawn image sizes, cell sizes (down to 3x9 pixels, ragged last cells, single-row cell grids) and windows
-    (0..2): kNN proposals, neighbour proposals and one BCD sweep against the oracle, bit for bit (scratch/fuzz_geoms.py runs
+    (0..2): kNN proposals, neighbour proposals and one BCD sweep against the oracle, bit for bit (scratch/fuzz_geoms.py (round 3, git history) runs
     more of them)."""
     O = oracle
     H, W, ch, cw, window, ngauss = geom

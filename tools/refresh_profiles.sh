@@ -3,8 +3,6 @@
 set -e
 T=${1:-r04}
 R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${T}_bench.json 2> $O/bench.err
-echo bench done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/st -o s --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --no-long-run --fixed-batch 0 --steps 16 --warmup 8 > $O/${T}_bench_under_rocprof.json 2> $O/st.err
 echo stats done
@@ -26,4 +24,8 @@ python3 tools/pmc_to_json.py $O/pf $O/pw $O/pmc_traffic.json "python3 bench.py $
 python3 tools/pmc_summary.py $O/pm > $O/${T}_pmc_mfma.txt
 python3 tools/pmc_knn_json.py $O/pk $O/pmc_knn.json
 rm -rf $O/st $O/st1 $O/pf $O/pw $O/pm $O/pk
+# the bench line LAST, with the summaries just collected in place (its traffic / clock / stale_profiles fields read them)
+cp $O/pmc_traffic.json $O/pmc_knn.json profiles/
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${T}_bench.json 2> $O/bench.err
+echo bench done
 tail -1 $O/${T}_bench.json | cut -c1-300
