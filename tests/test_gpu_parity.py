@@ -577,6 +577,42 @@ def test_knn_mfma_screen_is_exact_on_hard_descriptors(torch_, synth, monkeypatch
         assert np.array_equal(a[k], b[k]), (case, k)
 
 
+@pytest.mark.parametrize("seed", (1, 2, 3))
+def test_knn_mfma_screen_on_mixed_scale_rows(torch_, synth, seed):
+    """What low-texture frames do to the screen, exaggerated: per-PIXEL scales from 1e-7 to 2 (rows of a cell that differ by
+    seven orders of magnitude: fringes of flat regions next to texture), 15 % all-zero rows in both images, and exact
+    duplicates of non-zero rows among the candidates (ties that the index must break).  MFMA-screened search against the
+    brute-force kernel, bit for bit, and no list may have gone to the brute-force kernel inside the screened run."""
+    torch = torch_
+    L = pkg("_lib")
+    H, W, ch, cw = 96, 128, 12, 16
+    img1, img2, _ = synth.make_pair(H, W, seed=40 + seed, amp_x=8, amp_y=6)
+    df = make(H, W, ch, cw)
+    df.load_pair(img1, img2)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    d = []
+    for base in (df.descrs1.clone(), df.descrs2.clone()):
+        scale = torch.pow(10.0, torch.rand((H, W, 1), generator=g) * 7.3 - 7.0).to(base.device)
+        zero = (torch.rand((H, W, 1), generator=g) < 0.15).to(base.device)
+        d.append(torch.where(zero, torch.zeros_like(base), base * scale))
+    d1, d2 = d
+    # duplicates among the candidates: every fourth pixel repeats its left neighbour's row
+    d2[:, 1::4] = d2[:, 0:-1:4][:, :d2[:, 1::4].shape[1]]
+    out = []
+    for mode in (0, L.FLAG_KNN_EXACT):
+        df.p.flags = mode
+        df.set_descriptors(d1, d2)
+        df.generisi()
+        if mode == 0:
+            stats = df.knn_stats()
+        out.append(df.host_state())
+    df.p.flags = 0
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+    assert stats["flags"] == 0 and stats["lists_exact"] == 0, stats
+    assert stats["zero_queries"] > 0.1 * H * W and stats["zero_candidates_removed"] > 0, stats
+
+
 def test_large_frame_invariants(torch_, oracle, synth):
     """1920x1080 (2.07 Mpx, 36 GB workspace): 64-bit offsets everywhere, structural invariants and sampled parity with the
     oracle's exact search; guards against 32-bit index arithmetic that the benchmark sizes cannot reach."""
@@ -836,6 +872,30 @@ def test_cli_kitti_png_branch(torch_, oracle, synth, tmp_path, monkeypatch):
     assert np.array_equal(np.load("Daisy output slike 106 backward=1 lcosts_nakon_gausa.npy"), ref["lcosts"])
     assert np.array_equal(np.load("Daisy output slike 106 backward=1 nprop.npy"), ref["nprop"])
     assert np.array_equal(np.load("Gotova flow slika 106 backward=1 posle 00 BCD.npy"), ref["flows"][0])
+
+
+def test_integration_stub_runs_as_written(torch_, oracle, synth, tmp_path, monkeypatch):
+    """INTEGRATION.md section 2 is the binding a maintainer of the reference would paste next to `daisy i flann.py`: the code
+    block is executed here VERBATIM (only the library path is made absolute) with the module globals the reference has at
+    that point (pich, picw, cellh, cellw, pic3, pic4, bcd_times, picindex, backward, wstr, con_tresh), and the .npy it saves
+    must be the oracle's flow."""
+    import os, re
+    from conftest import ROOT, PKG
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# dflow_binding.py.*?)```", text, re.S).group(1)
+    block = block.replace('C.CDLL("libdflow.so")', 'C.CDLL(%r)' % os.path.join(ROOT, PKG, "csrc", "libdflow.so"))
+    H, W, ch, cw = 48, 64, 8, 8
+    img1, img2, _ = synth.make_pair(H, W, seed=4, amp_x=6, amp_y=4)
+    monkeypatch.chdir(tmp_path)
+    zeros = torch_.zeros((H, W, 2), dtype=torch_.float32, device="cuda:0")
+    ns = dict(pich=H, picw=W, cellh=ch, cellw=cw, pic3=img1, pic4=img2, bcd_times=2, picindex="06", backward="0", wstr="02",
+              con_tresh=10.0, flow_fwd=zeros, flow_bwd=zeros)
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    torch_.cuda.synchronize()
+    got = np.load("Gotova flow slika 106 backward=0 posle 02 BCD.npy")
+    ref = oracle.full_pass(oracle.make_params(H, W, ch, cw, seed=0), img1, img2, 2)
+    assert got.dtype == np.float64 and np.array_equal(got, ref["flows"][-1])
+    assert tuple(ns["sparse"].shape) == (H, W, 3)
 
 
 def test_baseline_config0_as_one_run(torch_, oracle, synth, tmp_path, monkeypatch):
