@@ -804,6 +804,7 @@ def other_configs(eng, args):
                           "lists_to_exact_search": st["lists_exact"], "whole_pass_fallback": bool(st["flags"] & 1),
                           "max_entries_per_lane": st["max_entries_per_lane"], "list_capacity_per_lane": st["list_capacity"],
                           "all_zero_queries": st["zero_queries"], "all_zero_candidates_removed": st["zero_candidates_removed"],
+                          "query_cell_pairs_with_a_wave_of_their_own": st["heavy_pairs"],
                           "note": "round 3's screen sent this frame's whole pass to the brute-force kernel (knn_fix_kernel 81 ms, "
                                   "profiles/r04_lowtex_round3_code.jsonl)"}
     # configs[4] geometry: 4 passes (2 pairs, both directions)

@@ -108,9 +108,10 @@ int dflow_knn_proposals_timed(const dflow_params *p, const void *d_descr1, const
  * [1] flags (bit 0: the whole pass went to the exact search: the basis failed its orthonormality check), [2] event lists of the
  * pass, [3] list entries written, [4] events = (query, candidate) pairs evaluated exactly, [5] most entries in one lane's list,
  * [6] all-zero queries (answered from their cells' own lists), [7] queries outside the screen's range, [8] all-zero candidate
- * rows, [9] of those removed as duplicates, [10] (query, cell) pairs of the pass, [11] list capacity per lane.
+ * rows, [9] of those removed as duplicates, [10] (query, cell) pairs of the pass, [11] list capacity per lane, [12] (query, cell)
+ * pairs with so many events that one wave took the query alone (its 64 lanes over the events).
  * No reference counterpart. */
-#define DFLOW_KNN_STATS_N 12
+#define DFLOW_KNN_STATS_N 13
 int dflow_knn_screen_stats(const dflow_params *p, void *d_ws, size_t ws_bytes, void *stream, int64_t *h_stats);
 
 /* nasumicni, daisy i flann.py:205-233: appends up to ngauss neighbour proposals per pixel (in place).

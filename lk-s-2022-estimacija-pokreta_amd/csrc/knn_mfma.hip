@@ -42,7 +42,10 @@
 //   resolve   (knn_resolve_kernel) one wave per (64 queries, window column): canonical float32 distance (sequential
 //             fmaf chain) and truncated L1 cost (numpy order) of every event, exact (distance, index) top-5 in
 //             registers, proposals [dy,dx] and costs into the cell's 5 slots (Q1-Q3).  The rows are fetched by the
-//             whole wave through LDS (see the kernel).
+//             whole wave through LDS (see the kernel).  A query with more than KM_HEAVY_ENTRIES list entries in a cell (fringes
+//             of flat regions: hundreds of near-ties) would hold its 63 neighbours for hundreds of rounds: it is handed to
+//             knn_resolve_heavy_kernel, one wave per (query, cell) with the lanes over the EVENTS and a merge of the 64 partial
+//             top-5 lists by the same keys.
 //   fix       lists that cannot be screened (a query or candidate outside the range the f16 rows cover, NaN: flagged per
 //             LIST by the prep kernel) are redone by the exact brute-force search (knn.hip), list by list -- never the whole
 //             pass, unless the basis itself fails its orthonormality check.  finalize sets nprop, the WTA label (first
@@ -681,6 +684,9 @@ struct KmResolve {
     int *ovf_count;                // lists for knn_fix_kernel: entries (qcell, first query, ci, cj); one slot per list of the pass
     int4 *ovf_list;
     int ovf_cap;
+    int *heavy_count;              // (query, cell) pairs with more than KM_HEAVY_ENTRIES list entries: (qcell, query index, ci, cj) for
+    int4 *heavy_list;              // knn_resolve_heavy_kernel, which spreads ONE query's events over the 64 lanes
+    int heavy_cap;
 };
 
 // sorted insertion of (key, cost) into an ascending top-5; key order = canonical (distance, index) order
@@ -708,6 +714,11 @@ __device__ static inline void key_insert(unsigned long long (&k)[5], float (&c)[
 //    (bytes 256..271) is fetched by its own lane.
 // One wave per block.  The arithmetic per (query, candidate) pair is that of knn_resolve_kernel and the top 5 are ordered
 // by the same (distance, index) keys, so the results are identical.
+#ifndef KM_HEAVY_ENTRIES
+#define KM_HEAVY_ENTRIES 32
+#endif
+                                 // a query with more list entries in a cell (fringes of flat regions: hundreds of events) leaves the
+                                 // lane-per-query kernel: 63 lanes would wait for it round after round
 #define KM_EVLIST2 30            // candidates per query and candidate cell listed in LDS at a time (more: further passes);
                                  // 30: stage + lists + offsets = 20 KB per wave = 8 waves per CU
 typedef float km_f2 __attribute__((ext_vector_type(2)));
@@ -768,7 +779,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
         const size_t lid = list_id(a, qcell, qwave, wslot);
         const int cy0 = g.y0(cj);
         const int ntiles = (ccw * (g.y1(cj) - cy0) + KM_CHUNK - 1) / KM_CHUNK * (KM_CHUNK / 32);   // as in the screen kernel
-        const int nA = nA_n, nB = nB_n;
+        int nA = nA_n, nB = nB_n;
         bool ovf = nA == 255 || nB == 255;
         const uint32_t *evA = p.ev + (size_t)lid * KM_LIST_WORDS(a.evrows) + (size_t)gq * a.evrows * 64 + col;
         uint32_t entA[4], entB[4];
@@ -781,6 +792,21 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
                 if (pos < p.ovf_cap) p.ovf_list[pos] = make_int4(qcell, qwave * KM_QPW, ci, cj);
             }
             continue;
+        }
+        // a query with very many events in this cell goes to knn_resolve_heavy_kernel (its lane idles here); if that kernel's
+        // list is full the query stays (slow, still exact)
+        bool heavy = false;
+        if (nA + nB > KM_HEAVY_ENTRIES) {
+            heavy = true;
+            if (qvalid) {
+                const int pos = atomicAdd(p.heavy_count, 1);
+                if (pos < p.heavy_cap) p.heavy_list[pos] = make_int4(qcell, qi, ci, cj); else heavy = false;
+            }
+            if (heavy) {
+                nA = 0; nB = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { entA[e] = 0u; entB[e] = 0u; }
+            }
         }
         unsigned long long keys[5];
         float costs[5];
@@ -859,7 +885,7 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
             for (int i = 0; i < 5; i++) { keys[i] = zt.idx[i]; costs[i] = zt.cost[i]; }
         }
         // ---- emit (daisy i flann.py:174-180)
-        if (qvalid) {
+        if (qvalid && !heavy) {
             const size_t pix = (size_t)qy * g.W + qx;
             const int slot_base = 5 * wslot;
 #pragma unroll
@@ -870,6 +896,145 @@ __global__ void __launch_bounds__(64, 2) knn_resolve_kernel(KmGeom a, KmResolve 
                 p.proposals[pix * a.LP + slot_base + j] = pack_flow(ty - qy, tx - qx);
                 p.lcosts[pix * a.LP + slot_base + j] = s < a.tphi ? s : a.tphi;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ resolve, heavy queries
+// One wave per (query, cell) pair that knn_resolve_kernel handed over: the query's row sits in every lane's registers, the
+// lanes take DIFFERENT candidates (64 events per round instead of one), every lane keeps the 5 best of those it saw, and the
+// 64 partial lists are merged at the end by five wave-wide minima over (distance, index) keys -- the same keys, so the same
+// five winners in the same order as the sequential scan.  Same arithmetic per pair as knn_resolve_kernel.
+#define KM_HEAVY_CAND 1024       // candidates expanded per batch: 64 list entries of up to 16 events
+template <bool F16>
+__global__ void __launch_bounds__(64, 2) knn_resolve_heavy_kernel(KmGeom a, KmResolve p)
+{
+    const Geom g = a.g;
+    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(1024))) char stage[F16 ? 16 : ROW_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cand[64];
+    __shared__ uint16_t cand[KM_HEAVY_CAND];
+    typename RowsOf<F16>::type rows;
+    constexpr uint32_t PIECES = RowsOf<F16>::PIECES;
+    rows.init(stage, s_cand, lane);
+    const int nitems = min(*p.heavy_count, p.heavy_cap);
+    const rs_gptr d2g = (rs_gptr)p.d2;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {          // wave-uniform
+        const int4 it = p.heavy_list[item];
+        const int qcell = it.x, qi = it.y, ci = it.z, cj = it.w;
+        const int qci = qcell % g.ncx, qcj = qcell / g.ncx;
+        const int qx0 = g.x0(qci), qy0 = g.y0(qcj), qcw = g.x1(qci) - qx0;
+        const int qy = qy0 + qi / qcw, qx = qx0 + qi % qcw;
+        const size_t qpix = (size_t)qy * g.W + qx;
+        const int cimin = max(0, qci - g.win), cjmin = max(0, qcj - g.win), cjmax = min(g.ncy - 1, qcj + g.win);
+        const int wslot = (ci - cimin) * (cjmax - cjmin + 1) + (cj - cjmin);
+        const int cx0 = g.x0(ci), cy0 = g.y0(cj), ccw = g.x1(ci) - cx0;
+        const int ntiles = (ccw * (g.y1(cj) - cy0) + KM_CHUNK - 1) / KM_CHUNK * (KM_CHUNK / 32);
+        const size_t lid = list_id(a, qcell, qi / KM_QPW, wslot);
+        const int ql = qi % KM_QPW, gq = ql >> 5, col = ql & 31;            // the query's lane in its list
+        const uint32_t *ev = p.ev + (size_t)lid * KM_LIST_WORDS(a.evrows) + (size_t)gq * a.evrows * 64 + col;
+        // the query's row, in every lane; the list lengths and the first 64 entries of both lists are requested beside it
+        // (one memory round trip instead of three)
+        float q[DFLOW_DESC];
+        int nA, nB;
+        uint32_t pre_a, pre_b;
+        {
+            rows.issue((rs_gptr)p.d1, (uint32_t)qpix * PIECES, true);
+            nA = p.ev_cnt[lid * 128 + gq * 64 + col]; nB = p.ev_cnt[lid * 128 + gq * 64 + col + 32];
+            const int te = min(lane, a.evrows - 1);
+            pre_a = ev[(size_t)te * 64]; pre_b = ev[(size_t)te * 64 + 32];
+            float4 qv[17];
+            rows.fetch(qv);
+#pragma unroll
+            for (int k = 0; k < 17; k++) { q[4 * k] = qv[k].x; q[4 * k + 1] = qv[k].y; q[4 * k + 2] = qv[k].z; q[4 * k + 3] = qv[k].w; }
+        }
+        unsigned long long keys[5];
+        float costs[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { keys[i] = 0x7F800000FFFFFFFFull; costs[i] = 0.0f; }
+        // batches of 64 list entries (first list, then second): lane = entry, its events' candidate indices go to LDS at the
+        // wave-wide prefix of the popcounts
+        for (int e0 = 0; e0 < nA + nB; e0 += 64) {
+            const int t = e0 + lane;
+            uint32_t en = 0u; int h = 0;
+            // entry t of the concatenated lists: the first 64 of each list are in the lanes' registers already
+            const uint32_t shb = (uint32_t)__shfl((int)pre_b, (t - nA) & 63);
+            if (t < nA) en = t < 64 ? pre_a : ev[(size_t)t * 64];
+            else if (t < nA + nB) { en = t - nA < 64 ? shb : ev[(size_t)(t - nA) * 64 + 32]; h = 1; }
+            const int cntl = t < nA + nB ? __popc(en & 0xFFFFu) : 0;
+            int incl = cntl;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+            const int nc = __shfl(incl, 63);                    // candidates of this batch (<= 1024)
+            {
+                int o = incl - cntl;
+                const int tile = (int)(en >> 16);
+                uint32_t m = t < nA + nB ? (en & 0xFFFFu) : 0u;
+                while (m) { const int r = __ffs(m) - 1; m &= m - 1; cand[o++] = (uint16_t)((4 * h + (r & 3) + 8 * (r >> 2)) * ntiles + tile); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // rounds of 64 candidates; the fetch of the next round overlaps this round's arithmetic
+            auto issue_cand = [&](int c0) -> int {
+                const bool act = c0 + lane < nc;
+                const int idx = act ? cand[c0 + lane] : 0;
+                rows.issue(d2g, (uint32_t)((cy0 + idx / ccw) * g.W + cx0 + idx % ccw) * PIECES, act);
+                return idx;
+            };
+            int idx_next = issue_cand(0);
+            for (int c0 = 0; c0 < nc; c0 += 64) {
+                float4 cv[17];
+                rows.fetch(cv);
+                const bool act = c0 + lane < nc;
+                const int idx = idx_next;
+                if (c0 + 64 < nc) idx_next = issue_cand(c0 + 64);
+                const float worst = __uint_as_float((unsigned)(keys[4] >> 32));
+                float acc = 0.0f, rs[8], tl[4];
+#pragma unroll
+                for (int k = 0; k < 17; k++) {
+                    const float4 v = cv[k];
+                    const km_f2 ea = (km_f2){q[4 * k], q[4 * k + 1]} - (km_f2){v.x, v.y};
+                    const km_f2 eb = (km_f2){q[4 * k + 2], q[4 * k + 3]} - (km_f2){v.z, v.w};
+                    const float d0 = ea.x, d1 = ea.y, d2 = eb.x, d3 = eb.y;
+                    acc = __fmaf_rn(d0, d0, acc); acc = __fmaf_rn(d1, d1, acc);
+                    acc = __fmaf_rn(d2, d2, acc); acc = __fmaf_rn(d3, d3, acc);
+                    const int j = (4 * k) & 7;
+                    if (k < 2) { rs[j] = fabsf(d0); rs[j + 1] = fabsf(d1); rs[j + 2] = fabsf(d2); rs[j + 3] = fabsf(d3); }
+                    else if (k < 16) { rs[j] = rs[j] + fabsf(d0); rs[j + 1] = rs[j + 1] + fabsf(d1); rs[j + 2] = rs[j + 2] + fabsf(d2); rs[j + 3] = rs[j + 3] + fabsf(d3); }
+                    else { tl[0] = fabsf(d0); tl[1] = fabsf(d1); tl[2] = fabsf(d2); tl[3] = fabsf(d3); }
+                }
+                if (act && !(acc > worst)) {
+                    float l1 = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+                    l1 = l1 + tl[0]; l1 = l1 + tl[1]; l1 = l1 + tl[2]; l1 = l1 + tl[3];
+                    key_insert(keys, costs, ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)idx, l1);
+                }
+            }
+        }
+        // ---- merge: five times the smallest head of the 64 sorted partial lists (keys are unique: the index is part of them)
+        unsigned long long rkey = 0x7F800000FFFFFFFFull;
+        float rcost = 0.0f;
+        for (int r = 0; r < 5; r++) {
+            unsigned long long m = keys[0];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(m, off); m = o < m ? o : m; }
+            const unsigned long long own = __ballot(keys[0] == m && m != 0x7F800000FFFFFFFFull);
+            float c = 0.0f;
+            if (own) {
+                const int wl = __ffsll((long long)own) - 1;
+                c = __shfl(costs[0], wl);
+                if (lane == wl) {                                 // pop
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { keys[i] = keys[i + 1]; costs[i] = costs[i + 1]; }
+                    keys[4] = 0x7F800000FFFFFFFFull; costs[4] = 0.0f;
+                }
+            }
+            if (lane == r) { rkey = m; rcost = c; }
+        }
+        // ---- emit (daisy i flann.py:174-180): lane j writes winner j
+        if (lane < 5) {
+            const int idx = (int)(rkey & 0xFFFFFFFFu);
+            const int ty = cy0 + idx / ccw, tx = cx0 + idx % ccw;
+            p.proposals[qpix * a.LP + 5 * wslot + lane] = pack_flow(ty - qy, tx - qx);
+            p.lcosts[qpix * a.LP + 5 * wslot + lane] = rcost < a.tphi ? rcost : a.tphi;
         }
     }
 }
@@ -927,6 +1092,8 @@ static size_t num_lists(const dflow_params *p)
     return (size_t)g.ncx * g.ncy * qwaves * win * win;
 }
 
+#define KM_HEAVY_BLOCKS 2048      // waves of knn_resolve_heavy_kernel (grid-stride over the pairs; 8 per CU)
+#define KM_HEAVY_CAP (1 << 20)    // (query, cell) pairs the cooperative kernel can take per pass (16 MB); more stay with knn_resolve_kernel
 // entries per lane of the event lists: one per tile of the largest cell, + 1 (the last entry of a list is never valid), so
 // that no list can run out; cells beyond KM_EVROWS_MAX - 1 tiles: KM_EVROWS_MAX
 static int km_evrows(const dflow_params *p)
@@ -947,6 +1114,7 @@ struct KmWs {
     void *pca_ws;
     KmCellTop *ztop;
     int4 *ovf;                  // one slot per list
+    int4 *heavy;                // KM_HEAVY_CAP (query, cell) pairs for knn_resolve_heavy_kernel
     uint32_t *ev;
     uint8_t *ev_cnt;
     size_t nl, bytes;
@@ -979,6 +1147,8 @@ static KmWs km_ws(const dflow_params *p, void *ws)
     k.ztop = (KmCellTop *)w; w += ncells * sizeof(KmCellTop);
     w = align256(w);
     k.ovf = (int4 *)w; w += k.nl * sizeof(int4);
+    w = align256(w);
+    k.heavy = (int4 *)w; w += (size_t)KM_HEAVY_CAP * sizeof(int4);
     w = align256(w);
     k.ev = (uint32_t *)w; w += k.nl * KM_LIST_WORDS(k.evrows) * sizeof(uint32_t);
     k.ev_cnt = (uint8_t *)w; w += k.nl * 128;
@@ -1042,9 +1212,15 @@ int launch_knn_mfma(const dflow_params *p, const void *d1, const void *d2, uint3
     KmResolve rs;
     rs.d1 = d1; rs.d2 = d2; rs.ev = k.ev; rs.ev_cnt = k.ev_cnt; rs.qs = k.qs; rs.ztop = k.ztop; rs.proposals = proposals; rs.lcosts = lcosts;
     rs.ovf_count = k.ctr; rs.ovf_list = k.ovf; rs.ovf_cap = (int)k.nl;
+    rs.heavy_count = k.ctr + 2; rs.heavy_list = k.heavy; rs.heavy_cap = KM_HEAVY_CAP;
     if (f16) hipLaunchKernelGGL(knn_resolve_kernel<true>, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
     else hipLaunchKernelGGL(knn_resolve_kernel<false>, dim3((unsigned)(g.ncx * g.ncy * win * a.qwaves)), dim3(64), 0, s, a, rs);
     rc = dflow_check_launch("knn_resolve_kernel");
+    if (rc) return rc;
+    // queries with hundreds of events in a cell (knn_resolve_kernel listed them): one wave each, its lanes over the events
+    if (f16) hipLaunchKernelGGL(knn_resolve_heavy_kernel<true>, dim3(KM_HEAVY_BLOCKS), dim3(64), 0, s, a, rs);
+    else hipLaunchKernelGGL(knn_resolve_heavy_kernel<false>, dim3(KM_HEAVY_BLOCKS), dim3(64), 0, s, a, rs);
+    rc = dflow_check_launch("knn_resolve_heavy_kernel");
     if (rc) return rc;
     mark(4);
     rc = launch_knn_fix(p, d1, d2, proposals, lcosts, k.ctr, k.ovf, (int)k.nl, k.ctr + 1, s);
@@ -1106,7 +1282,7 @@ int knn_mfma_stats(const dflow_params *p, void *ws, hipStream_t s, int64_t *h_ou
     int rc = dflow_check_launch("knn_stats kernels");
     if (rc) return rc;
     unsigned long long c[8];
-    int ctr[2];
+    int ctr[4];
     if (hipMemcpyAsync(c, dev, sizeof(c), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(ctr, k.ctr, sizeof(ctr), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
         return dflow_set_error(DFLOW_EHIP, "knn_mfma_stats: copy back failed");
@@ -1120,6 +1296,7 @@ int knn_mfma_stats(const dflow_params *p, void *ws, hipStream_t s, int64_t *h_ou
         }
     h_out[0] = ctr[0]; h_out[1] = ctr[1]; h_out[2] = (int64_t)k.nl; h_out[3] = (int64_t)c[0]; h_out[4] = (int64_t)c[1]; h_out[5] = (int64_t)c[2];
     h_out[6] = (int64_t)c[3]; h_out[7] = (int64_t)c[4]; h_out[8] = (int64_t)c[5]; h_out[9] = (int64_t)c[6]; h_out[10] = pairs; h_out[11] = k.evrows;
+    h_out[12] = ctr[2] < KM_HEAVY_CAP ? ctr[2] : KM_HEAVY_CAP;
     return DFLOW_OK;
 }
 

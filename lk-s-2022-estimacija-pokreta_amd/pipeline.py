@@ -134,7 +134,7 @@ class DiscreteFlow:
         return dict(zip(self.KNN_KERNELS, (float(v) for v in ms))), float(issued.value)
 
     KNN_STATS = ("lists_exact", "flags", "lists", "entries", "events", "max_entries_per_lane", "zero_queries", "bad_queries",
-                 "zero_candidates", "zero_candidates_removed", "query_cell_pairs", "list_capacity")
+                 "zero_candidates", "zero_candidates_removed", "query_cell_pairs", "list_capacity", "heavy_pairs")
 
     def knn_stats(self):
         """dflow_knn_screen_stats: what the MFMA screen of the last generisi() did (call before the next stage reuses the workspace)."""

@@ -1,7 +1,9 @@
 """kNN stage kernel by kernel (dflow_knn_proposals_timed) on a dense and a low-texture pair, then the other stages of the
-pass on the low-texture pair: python tools/knn_lowtex.py [HxW]"""
+pass on the low-texture pair: python tools/knn_lowtex.py [variant.so]"""
 import sys, os, json, importlib, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+_lib = importlib.import_module("lk-s-2022-estimacija-pokreta_amd._lib")
+if len(sys.argv) > 1 and sys.argv[1].endswith(".so"): _lib.LIB_PATH = os.path.join(ROOT, "tools", "prof_build", sys.argv[1])
 synth = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.synth")
 pl = importlib.import_module("lk-s-2022-estimacija-pokreta_amd.pipeline")
 H, W = 436, 1024
