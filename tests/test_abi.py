@@ -80,6 +80,28 @@ def test_batched_entry_points_validate_on_the_host(L):
     assert lib.dflow_bcd_phase_batch(C.byref(p), 2, None, arr, 0, arr, ws, None) == -1
 
 
+def test_knn_measurement_aids_validate_before_touching_the_gpu(L):
+    """dflow_knn_screen_stats / dflow_knn_proposals_timed describe the MFMA-screened search: with DFLOW_FLAG_KNN_EXACT, a null
+    output or a workspace that is too small they fail on the host."""
+    lib = L.lib()
+    p = L.default_params(64, 64, 8, 8)
+    out = (C.c_int64 * 13)()
+    assert lib.dflow_knn_screen_stats(C.byref(p), 1, 16, None, out) == -2 and b"workspace" in lib.dflow_last_error()
+    assert lib.dflow_knn_screen_stats(C.byref(p), 1, 1 << 40, None, None) == -1 and b"NULL" in lib.dflow_last_error()
+    q = L.default_params(64, 64, 8, 8, flags=L.FLAG_KNN_EXACT)
+    assert lib.dflow_knn_screen_stats(C.byref(q), 1, 1 << 40, None, out) == -1 and b"MFMA" in lib.dflow_last_error()
+    # the header's count of statistics is what the host mirror names
+    import re
+    header = open(os.path.join(ROOT, "include", "dflow.h")).read()
+    n = int(re.search(r"#define\s+DFLOW_KNN_STATS_N\s+(\d+)", header).group(1))
+    assert n == 13 and n == len(pkg("pipeline").DiscreteFlow.KNN_STATS)
+    # the workspace holds the event lists: one entry per tile of the largest cell + 1 per lane (no list can run out)
+    big = L.default_params(436, 1024, 27, 64)
+    tiles = -(-(31 * 64) // 192) * 6                        # the last cell row is 31 px high; cells are padded to 192 rows
+    nl = 16 * 16 * 31 * 25
+    assert lib.dflow_workspace_bytes(C.byref(big)) > nl * 2 * (tiles + 1) * 256
+
+
 def test_no_cpu_fallback(L):
     import torch
     if torch.cuda.is_available():
