@@ -46,6 +46,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise DflowError("%s is missing: run __graft_entry__.build() (there is no CPU fallback)" % LIB_PATH)
+        # torch brings its own copy of the HIP runtime (same SONAME as /opt/rocm's).  If libdflow.so is loaded first it pulls in
+        # the system copy, torch then loads its own, and whichever initialises second finds "no ROCm-capable device"
+        # (python __graft_entry__.py smoke = build() then smoke() in one process did exactly that).  torch first: one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int32
         pp = C.POINTER(Params)
