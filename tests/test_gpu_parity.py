@@ -318,6 +318,37 @@ def test_knn_lists_with_rows_outside_the_screen_go_to_the_exact_kernel_one_by_on
     assert s2["flags"] == 0 and 0 < s2["lists_exact"] <= 25 * waves_per_cell, s2
 
 
+def test_per_list_fallback_at_bench_size(torch_, synth):
+    """The per-LIST fallback at BASELINE size: 40 candidate pixels and 40 query pixels of the bench pair get a value the f16 rows
+    cannot hold; the lists they take part in (tens of thousands of the 198 400) go to knn_fix_kernel one by one, the rest
+    of the frame is screened as usual, and the whole frame equals the brute-force kernel's result (round 3 would have sent the
+    WHOLE pass to the brute-force kernel: one flag for the frame)."""
+    torch = torch_
+    L = pkg("_lib")
+    H, W = 436, 1024
+    img1, img2, _ = synth.make_pair(H, W, seed=synth.pair_seed(1, 0))
+    df = make(H, W, seed=0)
+    df.load_pair(img1, img2)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    d1, d2 = df.descrs1.clone(), df.descrs2.clone()
+    for d in (d1, d2):
+        ys = torch.randint(0, H, (40,), generator=g); xs = torch.randint(0, W, (40,), generator=g); ks = torch.randint(0, 68, (40,), generator=g)
+        d[ys, xs, ks] = 3000.0
+    out = {}
+    for mode in (0, L.FLAG_KNN_EXACT):
+        df.p.flags = mode
+        df.set_descriptors(d1, d2)
+        df.generisi()
+        if mode == 0:
+            stats = df.knn_stats()
+        out[mode] = [t.clone() for t in (df.proposals, df.lcosts, df.nprop, df.bestlabels)]
+    df.p.flags = 0
+    for a, b, name in zip(out[0], out[L.FLAG_KNN_EXACT], ("proposals", "lcosts", "nprop", "bestlabels")):
+        assert torch.equal(a, b), name
+    assert stats["flags"] == 0 and stats["bad_queries"] == 40, stats
+    assert 1000 < stats["lists_exact"] < 0.25 * stats["lists"], stats          # lists, not the pass
+
+
 def test_descriptor_storage_mode_is_fixed_at_construction(torch_):
     """Flipping DFLOW_FLAG_DESCR_F16 on an existing object would make the kernels use 272-byte rows in 144-byte planes (or
     the reverse): the wrapper refuses."""
